@@ -1,0 +1,94 @@
+"""Environment presets (reference: PY/builder/envs.py:26-130, PY/builder/building.py:7-64)."""
+
+from __future__ import annotations
+
+from metta_amd.config import (
+    ActionsConfig,
+    AgentConfig,
+    AgentRewards,
+    AssemblerConfig,
+    AttackActionConfig,
+    ChangeVibeActionConfig,
+    GameConfig,
+    InventoryConfig,
+    MettaGridConfig,
+    MoveActionConfig,
+    NoopActionConfig,
+    ProtocolConfig,
+    ResourceLimitsConfig,
+    WallConfig,
+)
+
+
+def _p(inputs: dict, outputs: dict, cooldown: int) -> ProtocolConfig:
+    return ProtocolConfig(input_resources=inputs, output_resources=outputs, cooldown=cooldown)
+
+
+def arena_objects() -> dict:
+    """Arena building set: building.py:7-58."""
+    return {
+        "wall": WallConfig(name="wall"),
+        "assembler": AssemblerConfig(name="assembler", protocols=[_p({"battery_red": 3}, {"heart": 1}, 10)]),
+        "mine_red": AssemblerConfig(name="mine_red", protocols=[_p({}, {"ore_red": 1}, 50)]),
+        "generator_red": AssemblerConfig(
+            name="generator_red", protocols=[_p({"ore_red": 1}, {"battery_red": 1}, 25)]
+        ),
+        "lasery": AssemblerConfig(name="lasery", protocols=[_p({"battery_red": 1, "ore_red": 2}, {"laser": 1}, 10)]),
+        "armory": AssemblerConfig(name="armory", protocols=[_p({"ore_red": 3}, {"armor": 1}, 10)]),
+    }
+
+
+def make_arena(num_agents: int, combat: bool = True, map_builder=None) -> MettaGridConfig:
+    """`make_arena` (envs.py:26-98): 25x25 rooms of 6 agents in a grid, border 6; heart reward 1."""
+    from metta_amd.mapgen import ArenaMapBuilder
+
+    actions = ActionsConfig(
+        noop=NoopActionConfig(),
+        move=MoveActionConfig(),
+        attack=AttackActionConfig(consumed_resources={"laser": 1}, defense_resources={"armor": 1}),
+        change_vibe=ChangeVibeActionConfig(enabled=False),
+    )
+    if not combat:
+        actions.attack.consumed_resources = {"laser": 100}
+    if map_builder is None:
+        map_builder = ArenaMapBuilder(
+            num_agents=num_agents,
+            width=25,
+            height=25,
+            border_width=6,
+            instance_border_width=0,
+            agents_per_instance=6,
+            objects={"wall": 10, "assembler": 5, "mine_red": 10, "generator_red": 5, "lasery": 1, "armory": 1},
+        )
+    return MettaGridConfig(
+        label="arena" + (".combat" if combat else ""),
+        game=GameConfig(
+            num_agents=num_agents,
+            actions=actions,
+            objects=arena_objects(),
+            agent=AgentConfig(
+                inventory=InventoryConfig(
+                    default_limit=50, limits={"heart": ResourceLimitsConfig(limit=255, resources=["heart"])}
+                ),
+                rewards=AgentRewards(inventory={"heart": 1}),
+            ),
+            map_builder=map_builder,
+        ),
+    )
+
+
+def make_navigation(num_agents: int) -> MettaGridConfig:
+    """`make_navigation` (envs.py:101-130): resources [heart]; one assembler {} -> heart, cooldown 255."""
+    from metta_amd.mapgen import RandomMapBuilder
+
+    nav_assembler = AssemblerConfig(name="assembler", protocols=[_p({}, {"heart": 1}, 255)])
+    return MettaGridConfig(
+        game=GameConfig(
+            num_agents=num_agents,
+            objects={"assembler": nav_assembler, "wall": WallConfig(name="wall")},
+            resource_names=["heart"],
+            actions=ActionsConfig(move=MoveActionConfig(enabled=True), noop=NoopActionConfig(enabled=True)),
+            agent=AgentConfig(rewards=AgentRewards(inventory={"heart": 1})),
+            map_builder=RandomMapBuilder(agents=num_agents),
+        )
+    )
