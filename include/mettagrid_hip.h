@@ -1,0 +1,117 @@
+/* mettagrid_hip.h -- C-ABI of the MI355X-native batched MettaGrid step path (libmettagrid_hip.so).
+ *
+ * Drop-in boundary for the reference's native environment core: the pybind11 class `MettaGrid`
+ * (packages/mettagrid/cpp/bindings/mettagrid_c.cpp:998-1093).  One handle owns E independent environments of one
+ * game configuration, resident in HBM; `mg_step` advances all of them by one tick.  Plain pointers and sizes only:
+ * any host language binds it with its FFI (ctypes stub: metta_amd/native.py; others: INTEGRATION.md).
+ *
+ * Conventions: every call returns 0 on success, non-zero on error; `mg_last_error()` then describes it
+ * (the reference throws std::runtime_error -> Python RuntimeError).  Device pointers returned by `mg_get_buffers`
+ * stay valid until `mg_destroy`.  `stream` is a hipStream_t passed as void* (NULL = the default stream); the
+ * step/reset calls are asynchronous on it.  A handle is thread-compatible (one caller at a time), no globals.
+ */
+#ifndef METTAGRID_HIP_H_
+#define METTAGRID_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_handle mg_handle;
+
+/* Device buffers of a handle (reference: the numpy buffers adopted by `MettaGrid::set_buffers`,
+ * mettagrid_c.cpp:721-738, and the pufferlib buffer set, pufferlib.py:18-45).  N = num_envs * num_agents. */
+typedef struct mg_buffers {
+  uint8_t* observations;   /* u8  [N][num_tokens][3]  (location, feature_id, value); 0xFF = empty      */
+  float* rewards;          /* f32 [N]                                                                  */
+  uint8_t* terminals;      /* u8  [N]  0/1  (numpy bool layout)                                        */
+  uint8_t* truncations;    /* u8  [N]  0/1                                                             */
+  int32_t* actions;        /* i32 [N]  INPUT: written by the caller before mg_step                     */
+  uint8_t* masks;          /* u8  [N]  all ones (reference: `MettaGrid::masks`, mettagrid_c.cpp:983-995) */
+  float* episode_rewards;  /* f32 [N]  (reference: `get_episode_rewards`, mettagrid_c.cpp:928-930)      */
+  uint8_t* action_success; /* u8  [N]  (reference: `action_success`, mettagrid_c.cpp:955-957)           */
+  int32_t num_envs, num_agents, num_tokens, num_actions;
+} mg_buffers;
+
+/* Last error message of the calling thread (never NULL). */
+const char* mg_last_error(void);
+
+/* Library version / build info string. */
+const char* mg_version(void);
+
+/* Create E environments from a packed game configuration (the int32 stream of csrc/mg_blob.h, written by
+ * metta_amd/compile.py).  Replaces `MettaGrid::MettaGrid(GameConfig, map, seed)` (mettagrid_c.cpp:46-155) for the
+ * config part; maps and seeds arrive through mg_set_maps / mg_reset.  `device_id` < 0 = current device. */
+int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int device_id, mg_handle** out);
+
+/* Upload a pool of P maps, each `height x width` uint8 cell codes (0 = empty; code -> object via the config's cell
+ * table), replacing the `list[list[str]]` map argument of the constructor (mettagrid_c.cpp:159-245).  Every map
+ * must hold exactly num_agents agent cells.  Object ids / agent ids follow row-major creation order. */
+int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int width);
+
+/* (Re)start environments: env_ids[n] (NULL = all E, then n is ignored), each with seeds[i] (std::mt19937 seed of
+ * the env, mettagrid_c.cpp:56-57) and map_ids[i] (index into the pool).  Computes the step-0 observations exactly
+ * like `_init_buffers` (mettagrid_c.cpp:264-289).  Host arrays. */
+int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds, const int32_t* map_ids, void* stream);
+
+/* Advance every environment one tick: `MettaGrid::step` (mettagrid_c.cpp:740-752, 572-678).  Reads the actions
+ * buffer in place; invalid action ids are not errors (stat + failed action, :605-608).  With auto-reset enabled an
+ * environment whose episode ended on the previous tick is first restarted (same seed, next map of the pool), which
+ * is `MettaGridPufferEnv.step` (python/src/mettagrid/envs/mettagrid_puffer_env.py:158-171). */
+int mg_step(mg_handle* h, void* stream);
+
+/* Auto-reset policy used by mg_step: enabled (0/1) and how the next map is chosen: map_id += map_stride (mod P). */
+int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride);
+
+/* Per-env step at which the FIRST episode is cut by setting all truncations (0 = never): the reference's
+ * EarlyResetHandler (python/src/mettagrid/envs/early_reset_handler.py:6-20).  Host array u32[E] or NULL to clear. */
+int mg_set_early_reset(mg_handle* h, const uint32_t* steps);
+
+/* Device pointers and shapes. */
+int mg_get_buffers(mg_handle* h, mg_buffers* out);
+
+/* `Simulation.end_episode` (simulator.py:134-136): set all truncations of one env (env < 0: all). */
+int mg_end_episode(mg_handle* h, int env, void* stream);
+
+/* Episode statistics of one env (reference: `get_episode_stats`, mettagrid_c.cpp:936-953), as raw slots:
+ * agent_values f32[A][n_agent_slots], agent_touched u8[A][n_agent_slots], game_values f32[n_game_slots],
+ * game_touched u8[n_game_slots]; slot -> key string tables live with the host language (metta_amd/stats.py).
+ * Synchronises the stream.  With `last_finished` != 0 returns the stats captured when the env's most recent
+ * episode ended (kept across the auto-reset), else the running episode's. */
+int mg_episode_stats(mg_handle* h, int env, int last_finished, float* agent_values, uint8_t* agent_touched,
+                     float* game_values, uint8_t* game_touched, void* stream);
+int mg_stat_slots(mg_handle* h, int* n_agent_slots, int* n_game_slots);
+
+/* Inspection (reference: `grid_objects`, mettagrid_c.cpp:754-918; `current_step`).  Host outputs; synchronises.
+ * agent_state: i32 [A][9 + 2R]: r, c, prev_r, prev_c, frozen, vibe, steps_without_motion, object id, n_items,
+ * then (item, amount) pairs in inventory iteration order (unused = -1).
+ * assembler_state: i32 [n][8]: r, c, cfg, object id, is_clipped, cooldown_end, cooldown_duration, uses_count. */
+int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream);
+int mg_num_assemblers(mg_handle* h, int env);
+int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream);
+int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, uint32_t* seed, uint32_t* episodes,
+                void* stream);
+
+/* `MettaGrid::set_inventory` (mettagrid_c.cpp:959-965; Agent::set_inventory, agent.cpp:54-72): items/amounts in
+ * the iteration order of the converted map (the host language orders them, metta_amd/umap.py). */
+int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* items, const int32_t* amounts, void* stream);
+
+/* Sum over all environments of the finished-episode accumulators since the last call with `clear` != 0:
+ * out f64[3 + n_game_slots] = {episodes, sum of episode lengths, sum of per-agent episode reward,
+ * sum of game stat slots...}.  This is the vector the multi-GPU path all-reduces. */
+int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream);
+
+/* Timing of the most recent mg_step's kernel in milliseconds (HIP events on the stream it was launched on);
+ * enable with mg_set_profiling(h, 1).  Used by bench.py for the roofline line. */
+int mg_set_profiling(mg_handle* h, int enabled);
+int mg_last_step_ms(mg_handle* h, float* ms);
+
+int mg_destroy(mg_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METTAGRID_HIP_H_ */

@@ -1,0 +1,222 @@
+"""`MettaGridBatch` -- E environments of one game configuration resident on one MI355X.
+
+Host-side counterpart of the reference's `MettaGrid` C++ object (`BIND/mettagrid_c.cpp:998-1093`), batched:
+the same accessors (`observations()/rewards()/terminals()/truncations()/actions()/masks()`,
+`get_episode_rewards()`, `get_episode_stats()`, `action_success()`, `set_inventory()`, `current_step`,
+`map_width/map_height`), but every buffer is a torch ROCm tensor aliasing the library's HBM buffers
+(zero-copy, `__cuda_array_interface__`), shaped `[E*A, ...]` like pufferlib's shared buffers
+(`PUF/pufferlib.py:18-45`).
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+from typing import Optional, Sequence
+
+import numpy as np
+
+from metta_amd import native
+from metta_amd.compile import CompiledGame, compile_game
+from metta_amd.stats_decode import decode_episode_stats
+from metta_amd.umap import order_from_pydict
+
+
+class _DevArray:
+    """Minimal `__cuda_array_interface__` carrier so torch can alias a raw device pointer."""
+
+    def __init__(self, ptr: int, shape: tuple, typestr: str, owner):
+        self.__cuda_array_interface__ = {
+            "shape": shape,
+            "typestr": typestr,
+            "data": (int(ptr), False),
+            "version": 3,
+            "strides": None,
+        }
+        self._owner = owner  # keeps the handle alive while tensors exist
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(ct.POINTER(t))
+
+
+class MettaGridBatch:
+    def __init__(
+        self,
+        cfg,
+        num_envs: int,
+        maps: Sequence,
+        device: int = 0,
+        init_obs_passes: int = 2,
+        seeds: Optional[Sequence[int]] = None,
+        map_ids: Optional[Sequence[int]] = None,
+        compiled: Optional[CompiledGame] = None,
+    ):
+        import torch
+
+        self._torch = torch
+        self.L = native.load()
+        self.compiled = compiled or compile_game(cfg, init_obs_passes=init_obs_passes)
+        self.num_envs = int(num_envs)
+        self.num_agents = self.compiled.num_agents
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.device_index)
+        blob = np.ascontiguousarray(self.compiled.blob, dtype=np.int32)
+        self._h = ct.c_void_p()
+        native.check(self.L.mg_create(_p(blob, ct.c_int32), blob.size, self.num_envs, self.device_index, ct.byref(self._h)))
+        self.set_maps(maps)
+        b = native.MgBuffers()
+        native.check(self.L.mg_get_buffers(self._h, ct.byref(b)))
+        N, T = self.num_envs * self.num_agents, self.compiled.num_tokens
+        self.num_actions = int(b.num_actions)
+
+        def alias(ptr, shape, typestr, dtype):
+            t = torch.as_tensor(_DevArray(ptr, shape, typestr, self), device=self.device)
+            assert t.dtype == dtype and t.data_ptr() == ptr
+            return t
+
+        self.observations = alias(b.observations, (N, T, 3), "|u1", torch.uint8)
+        self.rewards = alias(b.rewards, (N,), "<f4", torch.float32)
+        self.terminals = alias(b.terminals, (N,), "|b1", torch.bool)
+        self.truncations = alias(b.truncations, (N,), "|b1", torch.bool)
+        self.actions = alias(b.actions, (N,), "<i4", torch.int32)
+        self.masks = alias(b.masks, (N,), "|b1", torch.bool)
+        self.episode_rewards = alias(b.episode_rewards, (N,), "<f4", torch.float32)
+        self.action_success = alias(b.action_success, (N,), "|b1", torch.bool)
+        if seeds is not None or map_ids is not None:
+            self.reset(seeds=seeds, map_ids=map_ids)
+
+    # ---- maps / reset / step ---------------------------------------------------------------------------
+    def set_maps(self, maps: Sequence) -> None:
+        """`maps`: sequence of 2-D arrays, either uint8 cell codes or cell-name grids (reference `GameMap.grid`)."""
+        enc = []
+        for m in maps:
+            arr = np.asarray(m)
+            enc.append(arr.astype(np.uint8) if arr.dtype.kind in "ui" else self.compiled.encode_map(arr))
+        shapes = {e.shape for e in enc}
+        if len(shapes) != 1:
+            raise RuntimeError("all maps of a batch must share one (height, width)")
+        pool = np.ascontiguousarray(np.stack(enc), dtype=np.uint8)
+        self.map_pool = pool
+        self.map_height, self.map_width = pool.shape[1], pool.shape[2]
+        native.check(self.L.mg_set_maps(self._h, _p(pool, ct.c_uint8), pool.shape[0], pool.shape[1], pool.shape[2]))
+
+    def _stream(self) -> ct.c_void_p:
+        return ct.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, seeds=None, map_ids=None, env_ids=None) -> None:
+        """Restart environments (all by default).  Env i defaults to seed i and map i mod P."""
+        n = self.num_envs if env_ids is None else len(env_ids)
+        ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
+        base = np.arange(self.num_envs) if env_ids is None else np.asarray(env_ids)
+        s = np.ascontiguousarray(base if seeds is None else seeds, dtype=np.uint32)
+        m = np.ascontiguousarray(base % self.map_pool.shape[0] if map_ids is None else map_ids, dtype=np.int32)
+        if s.shape != (n,) or m.shape != (n,):
+            raise RuntimeError("seeds / map_ids must have one entry per environment being reset")
+        native.check(
+            self.L.mg_reset(self._h, None if ids is None else _p(ids, ct.c_int32), n, _p(s, ct.c_uint32), _p(m, ct.c_int32), self._stream())
+        )
+
+    def step(self, actions=None) -> None:
+        """One tick of every environment; `actions` (optional) is copied into the device action buffer."""
+        if actions is not None:
+            t = self._torch.as_tensor(actions)
+            if t.numel() != self.actions.numel():
+                raise RuntimeError("actions has the wrong shape")
+            self.actions.copy_(t.reshape(-1).to(dtype=self._torch.int32), non_blocking=True)
+        native.check(self.L.mg_step(self._h, self._stream()))
+
+    def set_auto_reset(self, enabled: bool, map_stride: int = 1) -> None:
+        native.check(self.L.mg_set_auto_reset(self._h, int(enabled), int(map_stride)))
+
+    def set_early_reset(self, steps: Optional[Sequence[int]]) -> None:
+        if steps is None:
+            native.check(self.L.mg_set_early_reset(self._h, None))
+        else:
+            s = np.ascontiguousarray(steps, dtype=np.uint32)
+            assert s.shape == (self.num_envs,)
+            native.check(self.L.mg_set_early_reset(self._h, _p(s, ct.c_uint32)))
+
+    def end_episode(self, env: int = -1) -> None:
+        native.check(self.L.mg_end_episode(self._h, int(env), self._stream()))
+
+    def set_profiling(self, enabled: bool) -> None:
+        native.check(self.L.mg_set_profiling(self._h, int(enabled)))
+
+    def last_step_ms(self) -> float:
+        ms = ct.c_float()
+        native.check(self.L.mg_last_step_ms(self._h, ct.byref(ms)))
+        return float(ms.value)
+
+    # ---- inspection ------------------------------------------------------------------------------------------
+    def env_info(self, env: int) -> dict:
+        step, mid, seed, eps = ct.c_uint32(), ct.c_int32(), ct.c_uint32(), ct.c_uint32()
+        native.check(
+            self.L.mg_env_info(self._h, env, ct.byref(step), ct.byref(mid), ct.byref(seed), ct.byref(eps), self._stream())
+        )
+        return {"current_step": step.value, "map_id": mid.value, "seed": seed.value, "episodes": eps.value}
+
+    def current_step(self, env: int) -> int:
+        return self.env_info(env)["current_step"]
+
+    def raw_stats(self, env: int, last_finished: bool = False):
+        A, Sa, Sg = self.num_agents, len(self.compiled.agent_slot_names[0]), len(self.compiled.game_slot_names)
+        av, at = np.zeros((A, Sa), np.float32), np.zeros((A, Sa), np.uint8)
+        gv, gt = np.zeros(Sg, np.float32), np.zeros(Sg, np.uint8)
+        native.check(
+            self.L.mg_episode_stats(
+                self._h, env, int(last_finished), _p(av, ct.c_float), _p(at, ct.c_uint8), _p(gv, ct.c_float),
+                _p(gt, ct.c_uint8), self._stream(),
+            )
+        )  # fmt: skip
+        return av, at, gv, gt
+
+    def agent_groups(self, env: int) -> list[int]:
+        mid = self.env_info(env)["map_id"]
+        flat = self.map_pool[mid].reshape(-1)
+        c = self.compiled
+        return [c.cell_group[int(v) - 1] for v in flat if v != 0 and c.cell_kinds[int(v) - 1] == 2]
+
+    def get_episode_stats(self, env: int, last_finished: bool = False) -> dict:
+        """`MettaGrid::get_episode_stats` (BIND/mettagrid_c.cpp:936-953) of one environment."""
+        av, at, gv, gt = self.raw_stats(env, last_finished)
+        return decode_episode_stats(self.compiled, av, at, gv, gt, self.agent_groups(env))
+
+    def agent_state(self, env: int) -> np.ndarray:
+        R = len(self.compiled.resource_names)
+        out = np.zeros((self.num_agents, 9 + 2 * R), np.int32)
+        native.check(self.L.mg_agent_state(self._h, env, _p(out, ct.c_int32), self._stream()))
+        return out
+
+    def assembler_state(self, env: int) -> np.ndarray:
+        n = self.L.mg_num_assemblers(self._h, env)
+        if n < 0:
+            raise RuntimeError("mg_num_assemblers failed")
+        out = np.zeros((max(n, 1), 8), np.int32)
+        if n:
+            native.check(self.L.mg_assembler_state(self._h, env, _p(out, ct.c_int32), self._stream()))
+        return out[:n]
+
+    def set_inventory(self, env: int, agent: int, inventory: dict[int, int]) -> None:
+        keys = order_from_pydict(list(inventory.keys()))
+        items = np.asarray(keys, dtype=np.int32)
+        amts = np.asarray([inventory[k] for k in keys], dtype=np.int32)
+        native.check(
+            self.L.mg_set_inventory(self._h, env, agent, len(keys), _p(items, ct.c_int32), _p(amts, ct.c_int32), self._stream())
+        )
+
+    def finished_summary(self, clear: bool = True) -> np.ndarray:
+        out = np.zeros(3 + len(self.compiled.game_slot_names), np.float64)
+        native.check(self.L.mg_finished_summary(self._h, _p(out, ct.c_double), int(clear), self._stream()))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.L.mg_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

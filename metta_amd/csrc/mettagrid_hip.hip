@@ -1,0 +1,1120 @@
+// mettagrid_hip.hip -- kernels + C-ABI of the MI355X-native batched MettaGrid step path (gfx950).
+//
+// Replaces, for the environment-step path, the reference's pybind11 core `MettaGrid`
+// (packages/mettagrid/cpp/bindings/mettagrid_c.cpp).  Layout and kernel design: DESIGN.md.
+//
+//   mg_step_kernel   one workgroup (4 waves) per environment:
+//       stage   static map tile (shared, L2-resident pool) + agent/assembler records -> LDS
+//       phase 1 thread 0 resolves the actions in the reference's shuffled sequential order on LDS state
+//       phase 2 each wave encodes whole agents' token rows into an LDS row buffer (wave prefix-sum compaction)
+//               and streams the 0xFF-padded 600-byte rows to HBM with coalesced dword stores
+//       phase 3 rewards, termination flags, stat flush, state write-back
+//
+// There is no CPU fallback: every entry point runs HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mettagrid_hip.h"
+#include "mg_blob.h"
+#include "mg_device_cfg.h"
+#include "mg_sim.h"
+
+#define MG_THREADS 256
+#define MG_WIN_MARGIN 32
+
+struct KArgs {
+  const int* dc;
+  const uint16_t* map_cells;  // [P][HW]
+  const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
+  const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
+  const int* map_nasm;        // [P]
+  const float* map_objcount;  // [P][n_cells]
+  int P, H, W, HW, NAmax, n_cells;
+  DEnv* env;
+  uint32_t* mt;  // [E][624]
+  DAgent* agents;
+  DAsm* asms;
+  float* astats;       // [E][A][SA]
+  uint32_t* atouched;  // [E][A][TW]
+  float* gstats;       // [E][SG]
+  uint32_t* gtouched;  // [E][GW]
+  float* fin_astats;
+  uint32_t* fin_atouched;
+  float* fin_gstats;
+  uint32_t* fin_gtouched;
+  float* fin_ep_rewards;  // [E][A]
+  uint32_t* fin_steps;    // [E]
+  double* summary;        // [3 + SG]
+  uint8_t* obs;
+  float* rewards;
+  uint8_t* term;
+  uint8_t* trunc;
+  const int* actions;
+  float* ep_rewards;
+  uint8_t* success;
+  int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
+  int auto_reset, map_stride;
+  const int* reset_envs;  // reset kernel only
+  const uint32_t* reset_seeds;
+  const int* reset_maps;
+};
+
+struct Lds {
+  uint16_t* grid;
+  DAgent* ag;
+  DAsm* as;
+  int* sd;
+  int* gd;
+  uint32_t* dirty_amt;
+  uint32_t* dirty_misc;
+  uint16_t* order;
+  int* exec;
+  int* tok_att;
+  uint32_t* win;
+  uint32_t* mtnext;
+  float* tokacc;  // [3] tokens_written / dropped / free_space accumulators
+  int* flags;     // [4]
+  uint8_t* rows;
+};
+
+__host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+__host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
+                                           int ROWB, int nwaves) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t sd = take((size_t)A * SA * 4), gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
+  size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
+  size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
+  if (l) {
+    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->sd = (int*)(base + sd);
+    l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
+    l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
+    l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
+    l->flags = (int*)(base + fl); l->rows = (uint8_t*)(base + rows);
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cooperative pieces (all threads of the workgroup)
+// ------------------------------------------------------------------------------------------------------------
+__device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, int tid, int nt) {
+  const uint16_t* src = a.map_cells + (size_t)map_id * a.HW;
+  int n2 = a.HW >> 1;
+  const uint32_t* s32 = (const uint32_t*)src;  // HW*2 bytes per map; maps start 4-byte aligned (HW even or padded)
+  uint32_t* d32 = (uint32_t*)l.grid;
+  if ((a.HW & 1) == 0) {
+    for (int i = tid; i < n2; i += nt) d32[i] = s32[i];
+  } else {
+    for (int i = tid; i < a.HW; i += nt) l.grid[i] = src[i];
+  }
+}
+
+__device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
+  for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = MG_CELL(MG_CELL_AGENT, i);
+}
+
+// All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
+__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, int map_id, uint32_t step, const int* exec,
+                                     bool write_global, int tid, int nt) {
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  uint8_t* row = l.rows + (size_t)wave * a.ROWB;
+  const int row_bytes = a.T * 3;
+  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  for (int ai = wave; ai < a.A; ai += nwaves) {
+    for (int i = lane; i < (a.ROWB >> 2); i += 64) ((uint32_t*)row)[i] = 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
+    int attempted =
+        mg_encode_agent(a.dc, l.grid, l.ag, l.as, asm_info, a.H, a.W, step, ai, exec ? exec[ai] : 0, row, lane);
+    if (lane == 0) l.tok_att[ai] = attempted;
+    __builtin_amdgcn_wave_barrier();
+    if (write_global) {
+      uint8_t* dst = a.obs + ((size_t)e * a.A + ai) * (size_t)row_bytes;
+      if ((row_bytes & 3) == 0) {
+        uint32_t* d32 = (uint32_t*)dst;
+        const uint32_t* s32 = (const uint32_t*)row;
+        for (int i = lane; i < (row_bytes >> 2); i += 64) d32[i] = s32[i];
+      } else {
+        for (int i = lane; i < row_bytes; i += 64) dst[i] = row[i];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
+// so that rounding above 2^24 matches the reference.  Thread 0 only.
+__device__ inline void mg_token_stats(const KArgs& a, const Lds& l, int passes) {
+  float w = l.tokacc[0], d = l.tokacc[1], f = l.tokacc[2];
+  for (int p = 0; p < passes; p++)
+    for (int i = 0; i < a.A; i++) {
+      int att = l.tok_att[i];
+      int wr = att < a.T ? att : a.T;
+      w += (float)wr;
+      d += (float)(att - wr);
+      f += (float)(a.T - wr);
+    }
+  l.tokacc[0] = w;
+  l.tokacc[1] = d;
+  l.tokacc[2] = f;
+}
+
+// Fresh episode state in LDS + zeroed global stats (MettaGrid ctor: bindings/mettagrid_c.cpp:46-155,159-245).
+__device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e, int map_id, uint32_t seed, int tid,
+                                    int nt) {
+  const int* dc = a.dc;
+  const int4* spawn = a.map_spawn + (size_t)map_id * a.A;
+  for (int i = tid; i < a.A; i += nt) {
+    int4 s = spawn[i];
+    DAgent ag;
+    memset(&ag, 0, sizeof(ag));
+    ag.r = ag.prev_r = (uint16_t)s.x;
+    ag.c = ag.prev_c = (uint16_t)s.y;
+    ag.group = (uint8_t)s.z;
+    ag.vibe = (uint8_t)group_rec(dc, s.z)[GR_INITIAL_VIBE];
+    ag.nb = 1;
+    l.ag[i] = ag;
+  }
+  int nasm = a.map_nasm[map_id];
+  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  for (int i = tid; i < a.NAmax; i += nt) {
+    DAsm s = {0, 0, 0, 0};
+    if (i < nasm) s.clipped = (uint32_t)asm_rec(dc, asm_info[i].z)[AR_START_CLIPPED];
+    l.as[i] = s;
+  }
+  for (int i = tid; i < a.A * a.SA; i += nt) l.sd[i] = 0;
+  for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  for (int i = tid; i < a.A; i += nt) {
+    l.dirty_amt[i] = 0;
+    l.dirty_misc[i] = 0;
+  }
+  // zero the running-episode stats in HBM
+  float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  for (int i = tid; i < a.A * a.SA; i += nt) as_[i] = 0.f;
+  uint32_t* at_ = a.atouched + (size_t)e * a.A * a.TW;
+  for (int i = tid; i < a.A * a.TW; i += nt) at_[i] = 0u;
+  float* gs_ = a.gstats + (size_t)e * a.SG;
+  uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.GW; i += nt) gt_[i] = 0u;
+  __syncthreads();
+  // objects.<cell name> counts (bindings/mettagrid_c.cpp:203,224,235)
+  const float* oc = a.map_objcount + (size_t)map_id * a.n_cells;
+  for (int i = tid; i < a.SG; i += nt) {
+    float v = 0.f;
+    int code = i - 3 + 1;
+    if (code >= 1 && code < a.n_cells && oc[code] > 0.f) {
+      v = oc[code];
+      atomicOr(&gt_[i >> 5], 1u << (i & 31));
+    }
+    gs_[i] = v;
+  }
+  for (int i = tid; i < a.A; i += nt) {
+    size_t g = (size_t)e * a.A + i;
+    a.rewards[g] = 0.f;
+    a.ep_rewards[g] = 0.f;
+    a.term[g] = 0;
+    a.trunc[g] = 0;
+    a.success[g] = 0;
+  }
+  if (tid == 0) {
+    l.tokacc[0] = l.tokacc[1] = l.tokacc[2] = 0.f;
+    // std::mt19937(seed): mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i
+    uint32_t* mt = a.mt + (size_t)e * 624;
+    uint32_t x = seed;
+    mt[0] = x;
+    for (int i = 1; i < 624; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      mt[i] = x;
+    }
+  }
+  // populate_initial_inventory (agent.cpp:48-52): ignore_limits, stat hooks fire; one thread per agent
+  for (int i = tid; i < a.A; i += nt) {
+    const int* gr = group_rec(dc, l.ag[i].group);
+    int oi = gr[GR_OFF_INITIAL], n = L_n(dc, oi);
+    for (int k = 0; k < n; k++) inv_update(cx, i, KV_k(dc, oi, k), KV_v(dc, oi, k), true);
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+// Push this step's stat deltas to HBM and mark touched keys.
+__device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& cx, int e, int tid, int nt) {
+  float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  uint32_t* at_ = a.atouched + (size_t)e * a.A * a.TW;
+  for (int i = tid; i < a.A * a.SA; i += nt) {
+    int v = l.sd[i];
+    if (v != 0) {
+      int ai = i / a.SA, s = i - ai * a.SA;
+      as_[i] += (float)v;
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+  }
+  for (int ai = tid; ai < a.A; ai += nt) {
+    uint32_t m = l.dirty_amt[ai];
+    while (m) {
+      int r = __ffs(m) - 1;
+      m &= m - 1;
+      int s = cx.AS.amount(r);
+      as_[ai * a.SA + s] = (float)l.ag[ai].amt[r];
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+    uint32_t dm = l.dirty_misc[ai];
+    if (dm & 1u) {
+      int s = cx.AS.diversity();
+      as_[ai * a.SA + s] = (float)l.ag[ai].diversity;
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+    if (dm & 2u) {
+      int s = cx.AS.max_steps_without_motion();
+      as_[ai * a.SA + s] = (float)l.ag[ai].max_swm;
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+  }
+  float* gs_ = a.gstats + (size_t)e * a.SG;
+  uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.SG; i += nt) {
+    int v = l.gd[i];
+    if (v != 0) {
+      gs_[i] += (float)v;
+      atomicOr(&gt_[i >> 5], 1u << (i & 31));
+    }
+  }
+  if (tid == 0) {
+    gs_[0] = l.tokacc[0];
+    gs_[1] = l.tokacc[1];
+    gs_[2] = l.tokacc[2];
+    atomicOr(&gt_[0], 7u);
+  }
+}
+
+__device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int map_id, uint32_t step) {
+  cx.dc = a.dc;
+  cx.grid = l.grid;
+  cx.ag = l.ag;
+  cx.as = l.as;
+  cx.asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  cx.sd = l.sd;
+  cx.gd = l.gd;
+  cx.dirty_amt = l.dirty_amt;
+  cx.dirty_misc = l.dirty_misc;
+  cx.H = a.H; cx.W = a.W; cx.A = a.A; cx.NA = a.NAmax; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG;
+  cx.step = step;
+  cx.asm_dirty = 0;
+  cx.AS = MgAgentSlots{a.R, a.NG};
+  cx.GS = MgGameSlots{a.R, a.n_cells - 1};
+}
+
+// Keep the finished episode's stats for the host and add it to the device-wide summary.
+__device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t steps, int tid, int nt) {
+  size_t na = (size_t)a.A * a.SA, nta = (size_t)a.A * a.TW;
+  const float* as_ = a.astats + (size_t)e * na;
+  float* fas = a.fin_astats + (size_t)e * na;
+  for (size_t i = tid; i < na; i += nt) fas[i] = as_[i];
+  const uint32_t* at_ = a.atouched + (size_t)e * nta;
+  uint32_t* fat = a.fin_atouched + (size_t)e * nta;
+  for (size_t i = tid; i < nta; i += nt) fat[i] = at_[i];
+  const float* gs_ = a.gstats + (size_t)e * a.SG;
+  float* fgs = a.fin_gstats + (size_t)e * a.SG;
+  for (int i = tid; i < a.SG; i += nt) {
+    float v = gs_[i];
+    fgs[i] = v;
+    if (v != 0.f) atomicAdd(&a.summary[3 + i], (double)v);
+  }
+  const uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  uint32_t* fgt = a.fin_gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.GW; i += nt) fgt[i] = gt_[i];
+  for (int i = tid; i < a.A; i += nt) {
+    float r = a.ep_rewards[(size_t)e * a.A + i];
+    a.fin_ep_rewards[(size_t)e * a.A + i] = r;
+    if (r != 0.f) atomicAdd(&a.summary[2], (double)r);
+  }
+  if (tid == 0) {
+    a.fin_steps[e] = steps;
+    atomicAdd(&a.summary[0], 1.0);
+    atomicAdd(&a.summary[1], (double)steps);
+  }
+}
+
+// Stage the window of MT19937 outputs this step may consume; twist cooperatively when it crosses the block end.
+__device__ inline void mg_stage_rng(const KArgs& a, const Lds& l, int e, uint32_t mt_idx, int tid, int nt) {
+  const uint32_t* mt = a.mt + (size_t)e * 624;
+  bool need_twist = (int)mt_idx + a.NWIN > 624;  // block-uniform
+  if (need_twist) {
+    for (int i = tid; i < 227; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+    __syncthreads();
+    for (int i = 227 + tid; i < 454; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+    __syncthreads();
+    for (int i = 454 + tid; i < 623; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+    __syncthreads();
+    if (tid == 0) l.mtnext[623] = mt_mix(mt[623], l.mtnext[0], l.mtnext[396]);
+    __syncthreads();
+  }
+  for (int i = tid; i < a.NWIN; i += nt) {
+    int j = (int)mt_idx + i;
+    uint32_t raw = j < 624 ? mt[j] : l.mtnext[(j - 624) % 624];
+    l.win[i] = mt_temper(raw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the step kernel
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
+  Lds l;
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6);
+  DEnv env = a.env[e];
+  const int* dc = a.dc;
+  Ctx cx;
+
+  const bool do_reset = a.auto_reset && env.done;  // block-uniform
+  if (do_reset) {
+    // MettaGridPufferEnv.step: `if terminals.all() or truncations.all(): self._new_sim()` before stepping
+    mg_snapshot_finished(a, e, env.step, tid, nt);
+    __syncthreads();
+    env.map_id = (uint32_t)(((int)env.map_id + a.map_stride) % a.P);
+    env.episodes += 1;
+    env.step = 0;
+    env.mt_idx = 624;
+    env.done = 0;
+    env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
+    mg_make_ctx(a, l, cx, (int)env.map_id, 0);
+    mg_load_grid(a, l, (int)env.map_id, tid, nt);
+    mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
+    mg_overlay_agents(a, l, tid, nt);
+    __syncthreads();
+    mg_encode_all(a, l, e, (int)env.map_id, 0, nullptr, false, tid, nt);
+    __syncthreads();
+    if (tid == 0) mg_token_stats(a, l, dc[DC_INIT_PASSES]);
+    __syncthreads();
+  } else {
+    mg_load_grid(a, l, (int)env.map_id, tid, nt);
+    const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
+    uint4* dst = (uint4*)l.ag;
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
+    uint4* d2 = (uint4*)l.as;
+    for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+    for (int i = tid; i < a.A * a.SA; i += nt) l.sd[i] = 0;
+    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+    for (int i = tid; i < a.A; i += nt) {
+      l.dirty_amt[i] = 0;
+      l.dirty_misc[i] = 0;
+    }
+    if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+    __syncthreads();
+    mg_overlay_agents(a, l, tid, nt);
+  }
+  mg_stage_rng(a, l, e, env.mt_idx, tid, nt);
+  env.step += 1;
+  mg_make_ctx(a, l, cx, (int)env.map_id, env.step);
+  __syncthreads();
+
+  // ---- phase 1: actions, in the reference's shuffled sequential order (bindings/mettagrid_c.cpp:588-622) ----
+  if (tid == 0) {
+    RngWin rng{l.win, a.NWIN, 0, 0};
+    mg_shuffle(l.order, a.A, rng);
+    const int n_actions = dc[DC_N_ACTIONS], oa = dc[DC_OFF_ACTIONS];
+    const int passes = dc[DC_MAX_PRIORITY] + 1;
+    const int* acts = a.actions + (size_t)e * a.A;
+    for (int i = 0; i < a.A; i++) l.exec[i] = 0;
+    for (int k = 0; k < a.A; k++) {
+      int ai = l.order[k];
+      int act = acts[ai];
+      bool ok = false;
+      if (act < 0 || act >= n_actions) {
+        // _handle_invalid_action runs once per priority level (the check precedes the priority filter)
+        int* sda = l.sd + ai * a.SA;
+        sda[cx.AS.invalid()] += passes;
+        int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
+        sda[cx.AS.invalid_variant(variant)] += passes;
+      } else {
+        ok = mg_handle_action(cx, ai, dc[oa + 2 * act], dc[oa + 2 * act + 1]);
+        if (ok) l.exec[ai] = act;
+      }
+      a.success[(size_t)e * a.A + ai] = ok ? 1 : 0;
+    }
+    // inventory regeneration (bindings/mettagrid_c.cpp:625-640)
+    int ri = dc[DC_REGEN_INTERVAL];
+    if (ri > 0 && env.step % (uint32_t)ri == 0) {
+      for (int ai = 0; ai < a.A; ai++) {
+        const int* gr = group_rec(dc, l.ag[ai].group);
+        int orr = gr[GR_OFF_REGEN], nr = dc[orr];
+        if (nr == 0) continue;
+        int lst = -1;
+        for (int q = 0; q < nr; q++)
+          if (dc[orr + 1 + 2 * q] == l.ag[ai].vibe) lst = dc[orr + 2 + 2 * q];
+        if (lst < 0)
+          for (int q = 0; q < nr; q++)
+            if (dc[orr + 1 + 2 * q] == 0) lst = dc[orr + 2 + 2 * q];
+        if (lst >= 0) {
+          int n = L_n(dc, lst);
+          for (int q = 0; q < n; q++) inv_update(cx, ai, KV_k(dc, lst, q), KV_v(dc, lst, q));
+        }
+      }
+    }
+    l.flags[0] = rng.used;
+    l.flags[1] = rng.overflow;
+    l.flags[2] = cx.asm_dirty;
+  }
+  __syncthreads();
+
+  // ---- phase 2: observations (bindings/mettagrid_c.cpp:557-563) ----------------------------------------------
+  mg_encode_all(a, l, e, (int)env.map_id, env.step, l.exec, true, tid, nt);
+  __syncthreads();
+  if (tid == 0) mg_token_stats(a, l, 1);
+  __syncthreads();
+
+  // ---- phase 3: rewards, flags, stats, write-back ----------------------------------------------------------
+  bool end_now = false, trunc_now = false;
+  {
+    int ms = dc[DC_MAX_STEPS];
+    if (ms > 0 && env.step >= (uint32_t)ms) {
+      end_now = true;
+      trunc_now = dc[DC_TRUNCATES] != 0;
+    }
+  }
+  bool early = env.early_reset != 0 && env.step >= env.early_reset;
+  const float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  const float* gs_ = a.gstats + (size_t)e * a.SG;
+  for (int ai = tid; ai < a.A; ai += nt) {
+    // Agent::compute_stat_rewards (agent.cpp:103-132)
+    DAgent* me = &l.ag[ai];
+    const int* gr = group_rec(dc, me->group);
+    int os = gr[GR_OFF_STAT_REWARDS], ns = dc[os];
+    float reward = 0.f;
+    if (ns > 0) {
+      float total = 0.f;
+      for (int q = 0; q < ns; q++) {
+        const int* sr = dc + os + 1 + 5 * q;
+        int aslot = sr[0], gslot = sr[1];
+        float v = 0.f;
+        if (aslot >= 0) {
+          if (aslot >= cx.AS.amount(0) && aslot < cx.AS.amount(0) + a.R)
+            v = (float)me->amt[aslot - cx.AS.amount(0)];
+          else if (aslot == cx.AS.max_steps_without_motion())
+            v = (float)me->max_swm;
+          else if (aslot == cx.AS.diversity())
+            v = (float)me->diversity;
+          else
+            v = as_[ai * a.SA + aslot] + (float)l.sd[ai * a.SA + aslot];
+        }
+        if (gslot >= 0) {
+          float gv = gslot < 3 ? l.tokacc[gslot] : gs_[gslot] + (float)l.gd[gslot];
+          v += gv;
+        }
+        float rew = v * __int_as_float(sr[2]);
+        if (sr[3]) {
+          float mx = __int_as_float(sr[4]);
+          rew = (mx < rew) ? mx : rew;
+        }
+        total += rew;
+      }
+      float delta = total - me->cur_reward;
+      if (delta != 0.0f) {
+        reward = delta;
+        me->cur_reward = total;
+      }
+    }
+    size_t g = (size_t)e * a.A + ai;
+    a.rewards[g] = reward;
+    a.ep_rewards[g] += reward;
+    if (end_now) {
+      if (trunc_now) a.trunc[g] = 1; else a.term[g] = 1;
+    }
+    if (early) a.trunc[g] = 1;
+  }
+  __syncthreads();
+  mg_flush_stats(a, l, cx, e, tid, nt);
+  {
+    uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
+    const uint4* src = (const uint4*)l.ag;
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    if (l.flags[2] || do_reset) {
+      uint4* d2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
+      const uint4* s2 = (const uint4*)l.as;
+      for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+    }
+    uint32_t new_idx = env.mt_idx + (uint32_t)l.flags[0];
+    if (new_idx > 624) {  // == 624: the block is exhausted but untwisted; the next step twists it
+      uint32_t* mt = a.mt + (size_t)e * 624;
+      for (int i = tid; i < 624; i += nt) mt[i] = l.mtnext[i];
+      new_idx -= 624;
+    }
+    if (tid == 0) {
+      env.mt_idx = new_idx;
+      if (end_now || early) env.done = 1;
+      if (early) env.early_reset = 0;
+      if (l.flags[1]) env.error |= 1u;
+      a.env[e] = env;
+    }
+  }
+}
+
+// Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.
+__global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
+  Lds l;
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6);
+  DEnv env = a.env[e];
+  env.seed = a.reset_seeds[blockIdx.x];
+  env.map_id = (uint32_t)a.reset_maps[blockIdx.x];
+  env.step = 0;
+  env.mt_idx = 624;
+  env.done = 0;
+  env.error = 0;
+  Ctx cx;
+  mg_make_ctx(a, l, cx, (int)env.map_id, 0);
+  mg_load_grid(a, l, (int)env.map_id, tid, nt);
+  mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
+  mg_overlay_agents(a, l, tid, nt);
+  __syncthreads();
+  mg_encode_all(a, l, e, (int)env.map_id, 0, nullptr, true, tid, nt);
+  __syncthreads();
+  if (tid == 0) mg_token_stats(a, l, a.dc[DC_INIT_PASSES]);
+  __syncthreads();
+  mg_flush_stats(a, l, cx, e, tid, nt);
+  uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
+  const uint4* src = (const uint4*)l.ag;
+  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+  uint4* d2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
+  const uint4* s2 = (const uint4*)l.as;
+  for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+  if (tid == 0) a.env[e] = env;
+}
+
+__global__ void mg_end_episode_kernel(KArgs a, int env) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.E * a.A) return;
+  int e = g / a.A;
+  if (env >= 0 && e != env) return;
+  a.trunc[g] = 1;
+  if (g % a.A == 0) a.env[e].done = 1;
+}
+
+// Agent::set_inventory (agent.cpp:54-72) for one agent, on HBM state (single thread; inspection/test API).
+__global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const int* items, const int* amounts) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (threadIdx.x != 0) return;
+  // minimal LDS context: one agent record and one row of stat deltas
+  DAgent* ag = (DAgent*)smem;
+  int* sd = (int*)(smem + mg_align16(sizeof(DAgent)));
+  uint32_t* dirty = (uint32_t*)(sd + a.SA);
+  *ag = a.agents[(size_t)e * a.A + agent];
+  for (int i = 0; i < a.SA; i++) sd[i] = 0;
+  dirty[0] = dirty[1] = 0;
+  Ctx cx;
+  cx.dc = a.dc; cx.grid = nullptr; cx.ag = ag; cx.as = nullptr; cx.asm_info = nullptr; cx.sd = sd; cx.gd = nullptr;
+  cx.dirty_amt = &dirty[0]; cx.dirty_misc = &dirty[1];
+  cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
+  cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1};
+  float* as_ = a.astats + ((size_t)e * a.A + agent) * a.SA;
+  uint32_t* at_ = a.atouched + ((size_t)e * a.A + agent) * a.TW;
+  uint8_t existing[MGD_MAX_R];
+  int ne = ag->n_items;
+  for (int i = 0; i < ne; i++) existing[i] = ag->order[i];
+  uint32_t zeroed = 0;
+  for (int i = 0; i < ne; i++) {
+    int item = existing[i];
+    inv_update(cx, 0, item, -(int)ag->amt[item]);
+    zeroed |= 1u << item;  // stats.set(<item>.amount, 0)
+  }
+  for (int i = 0; i < n; i++) inv_update(cx, 0, items[i], amounts[i] - (int)ag->amt[items[i]]);
+  for (int s = 0; s < a.SA; s++)
+    if (sd[s] != 0) {
+      as_[s] += (float)sd[s];
+      atomicOr(&at_[s >> 5], 1u << (s & 31));
+    }
+  uint32_t m = dirty[0] | zeroed;
+  while (m) {
+    int r = __ffs(m) - 1;
+    m &= m - 1;
+    int s = cx.AS.amount(r);
+    as_[s] = (float)ag->amt[r];
+    atomicOr(&at_[s >> 5], 1u << (s & 31));
+  }
+  if (dirty[1] & 1u) {
+    int s = cx.AS.diversity();
+    as_[s] = (float)ag->diversity;
+    atomicOr(&at_[s >> 5], 1u << (s & 31));
+  }
+  a.agents[(size_t)e * a.A + agent] = *ag;
+}
+
+__global__ void mg_fill_u8(uint8_t* p, size_t n, uint8_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+#define HIPCHK(x)                                                                                      \
+  do {                                                                                                 \
+    hipError_t _e = (x);                                                                               \
+    if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e));                 \
+  } while (0)
+
+struct mg_handle {
+  MgConfig cfg;
+  int device = 0;
+  int E = 0;
+  KArgs k;
+  std::vector<void*> allocs;
+  std::vector<void*> map_allocs;
+  size_t lds_bytes = 0;
+  bool maps_set = false;
+  bool profiling = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  std::vector<std::vector<int4>> host_spawn, host_asm;  // per map (inspection)
+  int* d_list = nullptr;       // scratch for reset lists [3][E]
+  int* d_inv = nullptr;        // scratch for set_inventory [2][MGD_MAX_R]
+  uint8_t* masks = nullptr;    // all ones (reference: mettagrid_c.cpp:983-995)
+};
+
+template <class T>
+static int dalloc(mg_handle* h, T** p, size_t n, bool map_alloc = false) {
+  void* q = nullptr;
+  size_t bytes = (n > 0 ? n : 1) * sizeof(T);
+  HIPCHK(hipMalloc(&q, bytes));
+  HIPCHK(hipMemset(q, 0, bytes));
+  (map_alloc ? h->map_allocs : h->allocs).push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+extern "C" {
+
+const char* mg_last_error(void) { return g_err.c_str(); }
+const char* mg_version(void) { return "mettagrid_hip 0.1 (gfx950; blob v" "3" ")"; }
+
+int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int device_id, mg_handle** out) {
+  if (!out) return fail("mg_create: out is NULL");
+  *out = nullptr;
+  if (num_envs < 1) return fail("mg_create: num_envs must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail("mg_create: no HIP device available (this library has no CPU fallback)");
+  auto h = std::make_unique<mg_handle>();
+  try {
+    h->cfg = MgConfig::parse(cfg_blob, cfg_words);
+  } catch (const std::exception& ex) {
+    return fail(std::string("mg_create: ") + ex.what());
+  }
+  const MgConfig& c = h->cfg;
+  if (c.R > MGD_MAX_R) return fail("mg_create: more than 16 resources are not supported on the device path yet");
+  if (!c.chests.empty()) return fail("mg_create: chest objects are not supported on the device path yet (SURVEY A19)");
+  for (const auto& g : c.groups)
+    if (!g.damage_threshold.empty() && !g.damage_resources.empty())
+      return fail("mg_create: agent damage is not supported on the device path yet");
+  if (c.A > MG_IDX_MASK) return fail("mg_create: too many agents per environment");
+  for (const auto& a : c.assemblers) {
+    if (a.chest_search_distance > 0 && !c.chests.empty()) return fail("mg_create: chest search unsupported");
+    for (const auto& p : a.protocols)
+      if (p.vibes.size() > 8) return fail("mg_create: protocols with more than 8 vibes are not supported");
+  }
+  if (device_id >= 0) {
+    HIPCHK(hipSetDevice(device_id));
+    h->device = device_id;
+  } else {
+    HIPCHK(hipGetDevice(&h->device));
+  }
+  h->E = num_envs;
+  KArgs& k = h->k;
+  memset(&k, 0, sizeof(k));
+  k.E = num_envs; k.A = c.A; k.T = c.T; k.SA = c.n_agent_slots; k.SG = c.n_game_slots; k.R = c.R; k.NG = c.n_group_names;
+  k.TW = (k.SA + 31) / 32; k.GW = (k.SG + 31) / 32; k.n_cells = (int)c.cells.size();
+  k.NWIN = std::min(624, c.A / 2 + 2 + MG_WIN_MARGIN);
+  if (c.A / 2 + 2 > 624) return fail("mg_create: too many agents for the RNG window");
+  k.ROWB = (int)mg_align16((size_t)c.T * 3);
+  k.auto_reset = 1; k.map_stride = 1;
+  std::vector<int32_t> dcfg = mg_build_dcfg(c);
+  int* d_dc = nullptr;
+  if (dalloc(h.get(), &d_dc, dcfg.size())) return 1;
+  HIPCHK(hipMemcpy(d_dc, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice));
+  k.dc = d_dc;
+  size_t N = (size_t)num_envs * c.A;
+  if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
+  if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
+  if (dalloc(h.get(), &k.agents, N)) return 1;
+  if (dalloc(h.get(), &k.astats, N * k.SA)) return 1;
+  if (dalloc(h.get(), &k.atouched, N * k.TW)) return 1;
+  if (dalloc(h.get(), &k.gstats, (size_t)num_envs * k.SG)) return 1;
+  if (dalloc(h.get(), &k.gtouched, (size_t)num_envs * k.GW)) return 1;
+  if (dalloc(h.get(), &k.fin_astats, N * k.SA)) return 1;
+  if (dalloc(h.get(), &k.fin_atouched, N * k.TW)) return 1;
+  if (dalloc(h.get(), &k.fin_gstats, (size_t)num_envs * k.SG)) return 1;
+  if (dalloc(h.get(), &k.fin_gtouched, (size_t)num_envs * k.GW)) return 1;
+  if (dalloc(h.get(), &k.fin_ep_rewards, N)) return 1;
+  if (dalloc(h.get(), &k.fin_steps, (size_t)num_envs)) return 1;
+  if (dalloc(h.get(), &k.summary, (size_t)(3 + k.SG))) return 1;
+  if (dalloc(h.get(), &k.obs, N * c.T * 3)) return 1;
+  if (dalloc(h.get(), &k.rewards, N)) return 1;
+  if (dalloc(h.get(), &k.term, N)) return 1;
+  if (dalloc(h.get(), &k.trunc, N)) return 1;
+  {
+    int* acts = nullptr;
+    if (dalloc(h.get(), &acts, N)) return 1;
+    k.actions = acts;
+  }
+  if (dalloc(h.get(), &k.ep_rewards, N)) return 1;
+  if (dalloc(h.get(), &k.success, N)) return 1;
+  if (dalloc(h.get(), &h->d_list, (size_t)num_envs * 3)) return 1;
+  if (dalloc(h.get(), &h->d_inv, (size_t)2 * MGD_MAX_R)) return 1;
+  HIPCHK(hipMemset(k.obs, 0xFF, N * c.T * 3));
+  if (dalloc(h.get(), &h->masks, N)) return 1;
+  HIPCHK(hipMemset(h->masks, 1, N));
+  HIPCHK(hipEventCreate(&h->ev0));
+  HIPCHK(hipEventCreate(&h->ev1));
+  *out = h.release();
+  return 0;
+}
+
+int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int width) {
+  if (!h) return fail("mg_set_maps: NULL handle");
+  if (num_maps < 1 || height < 1 || width < 1) return fail("mg_set_maps: bad dimensions");
+  if (height > 65535 || width > 65535) return fail("mg_set_maps: map too large");
+  HIPCHK(hipSetDevice(h->device));
+  const MgConfig& c = h->cfg;
+  KArgs& k = h->k;
+  const int HW = height * width;
+  const int HWp = (HW + 1) & ~1;  // keep each map 4-byte aligned
+  std::vector<uint16_t> cells((size_t)num_maps * HWp, 0);
+  std::vector<int4> spawn((size_t)num_maps * c.A);
+  std::vector<std::vector<int4>> asm_lists((size_t)num_maps);
+  std::vector<float> objcount((size_t)num_maps * c.cells.size(), 0.f);
+  h->host_spawn.assign((size_t)num_maps, {});
+  for (int m = 0; m < num_maps; m++) {
+    const uint8_t* src = maps + (size_t)m * HW;
+    uint32_t next_id = 1;
+    int n_agents = 0;
+    for (int r = 0; r < height; r++)
+      for (int cc = 0; cc < width; cc++) {
+        int code = src[(size_t)r * width + cc];
+        if (code == 0) continue;
+        if ((size_t)code >= c.cells.size())
+          return fail("Unknown object type: cell code " + std::to_string(code) + " in map " + std::to_string(m));
+        const MgCell& cell = c.cells[(size_t)code];
+        uint32_t id = next_id++;
+        uint16_t* dst = &cells[(size_t)m * HWp + (size_t)r * width + cc];
+        switch (cell.kind) {
+          case MG_CELL_WALL:
+            *dst = MG_CELL(MG_CELL_WALL, cell.idx);
+            objcount[(size_t)m * c.cells.size() + code] += 1.f;
+            break;
+          case MG_CELL_AGENT:
+            if (n_agents < c.A) spawn[(size_t)m * c.A + n_agents] = make_int4(r, cc, cell.idx, (int)id);
+            n_agents++;
+            break;
+          case MG_CELL_ASSEMBLER:
+            if (asm_lists[(size_t)m].size() >= (size_t)MG_IDX_MASK) return fail("mg_set_maps: too many assemblers");
+            *dst = MG_CELL(MG_CELL_ASSEMBLER, (int)asm_lists[(size_t)m].size());
+            asm_lists[(size_t)m].push_back(make_int4(r, cc, cell.idx, (int)id));
+            objcount[(size_t)m * c.cells.size() + code] += 1.f;
+            break;
+          default:
+            return fail("mg_set_maps: unsupported object kind in map");
+        }
+      }
+    if (n_agents != c.A)
+      return fail("mg_set_maps: map " + std::to_string(m) + " holds " + std::to_string(n_agents) +
+                  " agents but the config says num_agents = " + std::to_string(c.A));
+    h->host_spawn[(size_t)m].assign(spawn.begin() + (size_t)m * c.A, spawn.begin() + (size_t)(m + 1) * c.A);
+  }
+  int NAmax = 1;
+  for (auto& v : asm_lists) NAmax = std::max(NAmax, (int)v.size());
+  std::vector<int4> asm_flat((size_t)num_maps * NAmax, make_int4(0, 0, 0, 0));
+  std::vector<int> nasm((size_t)num_maps);
+  for (int m = 0; m < num_maps; m++) {
+    nasm[(size_t)m] = (int)asm_lists[(size_t)m].size();
+    for (size_t i = 0; i < asm_lists[(size_t)m].size(); i++) asm_flat[(size_t)m * NAmax + i] = asm_lists[(size_t)m][i];
+  }
+  h->host_asm = asm_lists;
+  // LDS budget
+  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64);
+  if (lds > 160 * 1024)
+    return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
+  for (void* p : h->map_allocs) (void)hipFree(p);
+  h->map_allocs.clear();
+  uint16_t* d_cells; int4* d_spawn; int4* d_asm; int* d_nasm; float* d_obj; DAsm* d_asms;
+  if (dalloc(h, &d_cells, cells.size(), true)) return 1;
+  if (dalloc(h, &d_spawn, spawn.size(), true)) return 1;
+  if (dalloc(h, &d_asm, asm_flat.size(), true)) return 1;
+  if (dalloc(h, &d_nasm, nasm.size(), true)) return 1;
+  if (dalloc(h, &d_obj, objcount.size(), true)) return 1;
+  if (dalloc(h, &d_asms, (size_t)h->E * NAmax, true)) return 1;
+  HIPCHK(hipMemcpy(d_cells, cells.data(), cells.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_spawn, spawn.data(), spawn.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_asm, asm_flat.data(), asm_flat.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_nasm, nasm.data(), nasm.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_obj, objcount.data(), objcount.size() * 4, hipMemcpyHostToDevice));
+  k.map_cells = d_cells; k.map_spawn = d_spawn; k.map_asm = d_asm; k.map_nasm = d_nasm; k.map_objcount = d_obj;
+  k.asms = d_asms;
+  k.P = num_maps; k.H = height; k.W = width; k.HW = HWp; k.NAmax = NAmax;
+  h->lds_bytes = lds;
+  HIPCHK(hipFuncSetAttribute((const void*)mg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  h->maps_set = true;
+  return 0;
+}
+
+int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds, const int32_t* map_ids, void* stream) {
+  if (!h) return fail("mg_reset: NULL handle");
+  if (!h->maps_set) return fail("mg_reset: call mg_set_maps first");
+  if (!seeds || !map_ids) return fail("mg_reset: seeds and map_ids are required");
+  HIPCHK(hipSetDevice(h->device));
+  if (!env_ids) n = h->E;
+  if (n < 1 || n > h->E) return fail("mg_reset: bad environment count");
+  for (int i = 0; i < n; i++) {
+    if (env_ids && (env_ids[i] < 0 || env_ids[i] >= h->E)) return fail("mg_reset: environment id out of range");
+    if (map_ids[i] < 0 || map_ids[i] >= h->k.P) return fail("mg_reset: map id out of range");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int* d = h->d_list;
+  HIPCHK(hipStreamSynchronize(s));
+  if (env_ids) HIPCHK(hipMemcpy(d, env_ids, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + h->E, seeds, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d + 2 * (size_t)h->E, map_ids, (size_t)n * 4, hipMemcpyHostToDevice));
+  KArgs k = h->k;
+  k.reset_envs = env_ids ? d : nullptr;
+  k.reset_seeds = (const uint32_t*)(d + h->E);
+  k.reset_maps = d + 2 * (size_t)h->E;
+  hipLaunchKernelGGL(mg_reset_kernel, dim3((unsigned)n), dim3(MG_THREADS), h->lds_bytes, s, k);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));  // the scratch lists are reused by the next call
+  return 0;
+}
+
+int mg_step(mg_handle* h, void* stream) {
+  if (!h) return fail("mg_step: NULL handle");
+  if (!h->maps_set) return fail("mg_step: call mg_set_maps and mg_reset first");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->profiling) (void)hipEventRecord(h->ev0, s);
+  hipLaunchKernelGGL(mg_step_kernel, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_bytes, s, h->k);
+  if (h->profiling) {
+    (void)hipEventRecord(h->ev1, s);
+    h->ev_valid = true;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride) {
+  if (!h) return fail("mg_set_auto_reset: NULL handle");
+  h->k.auto_reset = enabled ? 1 : 0;
+  h->k.map_stride = map_stride;
+  return 0;
+}
+
+int mg_set_early_reset(mg_handle* h, const uint32_t* steps) {
+  if (!h) return fail("mg_set_early_reset: NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<DEnv> envs((size_t)h->E);
+  HIPCHK(hipMemcpy(envs.data(), h->k.env, envs.size() * sizeof(DEnv), hipMemcpyDeviceToHost));
+  for (int e = 0; e < h->E; e++) envs[(size_t)e].early_reset = steps ? steps[e] : 0;
+  HIPCHK(hipMemcpy(h->k.env, envs.data(), envs.size() * sizeof(DEnv), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mg_get_buffers(mg_handle* h, mg_buffers* out) {
+  if (!h || !out) return fail("mg_get_buffers: NULL argument");
+  static_assert(sizeof(int) == 4, "int32");
+  out->observations = h->k.obs;
+  out->rewards = h->k.rewards;
+  out->terminals = h->k.term;
+  out->truncations = h->k.trunc;
+  out->actions = (int32_t*)h->k.actions;
+  out->masks = h->masks;
+  out->episode_rewards = h->k.ep_rewards;
+  out->action_success = h->k.success;
+  out->num_envs = h->E;
+  out->num_agents = h->cfg.A;
+  out->num_tokens = h->cfg.T;
+  out->num_actions = (int32_t)h->cfg.actions.size();
+  return 0;
+}
+
+int mg_end_episode(mg_handle* h, int env, void* stream) {
+  if (!h) return fail("mg_end_episode: NULL handle");
+  if (env >= h->E) return fail("mg_end_episode: environment id out of range");
+  int N = h->E * h->cfg.A;
+  hipLaunchKernelGGL(mg_end_episode_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->k, env);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int mg_stat_slots(mg_handle* h, int* n_agent_slots, int* n_game_slots) {
+  if (!h) return fail("mg_stat_slots: NULL handle");
+  if (n_agent_slots) *n_agent_slots = h->k.SA;
+  if (n_game_slots) *n_game_slots = h->k.SG;
+  return 0;
+}
+
+int mg_episode_stats(mg_handle* h, int env, int last_finished, float* agent_values, uint8_t* agent_touched,
+                     float* game_values, uint8_t* game_touched, void* stream) {
+  if (!h) return fail("mg_episode_stats: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_episode_stats: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  size_t na = (size_t)k.A * k.SA, nta = (size_t)k.A * k.TW;
+  std::vector<uint32_t> at(nta), gt((size_t)k.GW);
+  HIPCHK(hipMemcpy(agent_values, (last_finished ? k.fin_astats : k.astats) + (size_t)env * na, na * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(at.data(), (last_finished ? k.fin_atouched : k.atouched) + (size_t)env * nta, nta * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(game_values, (last_finished ? k.fin_gstats : k.gstats) + (size_t)env * k.SG, (size_t)k.SG * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(gt.data(), (last_finished ? k.fin_gtouched : k.gtouched) + (size_t)env * k.GW, (size_t)k.GW * 4, hipMemcpyDeviceToHost));
+  for (int a = 0; a < k.A; a++)
+    for (int s = 0; s < k.SA; s++) agent_touched[(size_t)a * k.SA + s] = (at[(size_t)a * k.TW + (s >> 5)] >> (s & 31)) & 1u;
+  for (int s = 0; s < k.SG; s++) game_touched[s] = (gt[(size_t)(s >> 5)] >> (s & 31)) & 1u;
+  return 0;
+}
+
+int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, uint32_t* seed, uint32_t* episodes,
+                void* stream) {
+  if (!h) return fail("mg_env_info: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_env_info: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  DEnv d;
+  HIPCHK(hipMemcpy(&d, h->k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  if (d.error) return fail("environment " + std::to_string(env) + " flagged an internal error (RNG window overflow)");
+  if (current_step) *current_step = d.step;
+  if (map_id) *map_id = (int32_t)d.map_id;
+  if (seed) *seed = d.seed;
+  if (episodes) *episodes = d.episodes;
+  return 0;
+}
+
+int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream) {
+  if (!h) return fail("mg_agent_state: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_agent_state: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  std::vector<DAgent> ag((size_t)k.A);
+  DEnv d;
+  HIPCHK(hipMemcpy(ag.data(), k.agents + (size_t)env * k.A, ag.size() * sizeof(DAgent), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  int R = k.R, stride = 9 + 2 * R;
+  for (int i = 0; i < k.A; i++) {
+    const DAgent& a = ag[(size_t)i];
+    int32_t* o = out + (size_t)i * stride;
+    o[0] = a.r; o[1] = a.c; o[2] = a.prev_r; o[3] = a.prev_c; o[4] = a.frozen; o[5] = a.vibe; o[6] = (int32_t)a.swm;
+    o[7] = h->host_spawn[(size_t)d.map_id][(size_t)i].w;
+    o[8] = a.n_items;
+    for (int q = 0; q < 2 * R; q++) o[9 + q] = -1;
+    for (int q = 0; q < a.n_items && q < R; q++) {
+      o[9 + 2 * q] = a.order[q];
+      o[9 + 2 * q + 1] = a.amt[a.order[q]];
+    }
+  }
+  return 0;
+}
+
+int mg_num_assemblers(mg_handle* h, int env) {
+  if (!h || env < 0 || env >= h->E) return -1;
+  DEnv d;
+  if (hipMemcpy(&d, h->k.env + env, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)h->host_asm[(size_t)d.map_id].size();
+}
+
+int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream) {
+  if (!h) return fail("mg_assembler_state: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_assembler_state: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  DEnv d;
+  HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  const auto& lst = h->host_asm[(size_t)d.map_id];
+  std::vector<DAsm> as((size_t)k.NAmax);
+  HIPCHK(hipMemcpy(as.data(), k.asms + (size_t)env * k.NAmax, as.size() * sizeof(DAsm), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < lst.size(); i++) {
+    int32_t* o = out + i * 8;
+    o[0] = lst[i].x; o[1] = lst[i].y; o[2] = lst[i].z; o[3] = lst[i].w; o[4] = (int32_t)as[i].clipped;
+    o[5] = (int32_t)as[i].cooldown_end; o[6] = (int32_t)as[i].cooldown_duration; o[7] = (int32_t)as[i].uses_count;
+  }
+  return 0;
+}
+
+int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* items, const int32_t* amounts, void* stream) {
+  if (!h) return fail("mg_set_inventory: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_set_inventory: environment id out of range");
+  if (agent < 0 || agent >= h->cfg.A) return 0;  // reference ignores unknown agents (mettagrid_c.cpp:961)
+  if (n < 0 || n > MGD_MAX_R) return fail("mg_set_inventory: too many items");
+  for (int i = 0; i < n; i++)
+    if (items[i] < 0 || items[i] >= h->cfg.R) return fail("mg_set_inventory: item id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipStreamSynchronize(s));
+  if (n > 0) {
+    HIPCHK(hipMemcpy(h->d_inv, items, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_inv + MGD_MAX_R, amounts, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  size_t lds = mg_align16(sizeof(DAgent)) + (size_t)h->k.SA * 4 + 16;
+  hipLaunchKernelGGL(mg_set_inventory_kernel, dim3(1), dim3(64), lds, s, h->k, env, agent, n, h->d_inv, h->d_inv + MGD_MAX_R);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream) {
+  if (!h || !out) return fail("mg_finished_summary: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  size_t n = (size_t)(3 + h->k.SG);
+  HIPCHK(hipMemcpy(out, h->k.summary, n * 8, hipMemcpyDeviceToHost));
+  if (clear) HIPCHK(hipMemset(h->k.summary, 0, n * 8));
+  return 0;
+}
+
+int mg_set_profiling(mg_handle* h, int enabled) {
+  if (!h) return fail("mg_set_profiling: NULL handle");
+  h->profiling = enabled != 0;
+  h->ev_valid = false;
+  return 0;
+}
+
+int mg_last_step_ms(mg_handle* h, float* ms) {
+  if (!h || !ms) return fail("mg_last_step_ms: NULL argument");
+  if (!h->ev_valid) return fail("mg_last_step_ms: profiling is off or no step was issued");
+  HIPCHK(hipEventSynchronize(h->ev1));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int mg_destroy(mg_handle* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (void* p : h->map_allocs) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return 0;
+}
+
+}  // extern "C"

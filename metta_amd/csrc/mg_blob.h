@@ -41,47 +41,47 @@ enum MgFid {
 #define MG_INVALID_VARIANTS 9  // action.invalid_index.<id> for id = -1, n_actions .. n_actions+6, "other"
 struct MgAgentSlots {
   int R, G;
-  int success(int h) const { return h; }
-  int failed(int h) const { return 3 + h; }
-  int failed_any() const { return 6; }
-  int invalid() const { return 7; }
-  int invalid_variant(int v) const { return 8 + v; }
-  int swap() const { return 17; }
-  int frozen_ticks() const { return 18; }
-  int frozen_ticks_group() const { return 19; }
-  int max_steps_without_motion() const { return 20; }
-  int diversity() const { return 21; }
-  int damage_triggered() const { return 22; }
-  int damage_items_lost() const { return 23; }
-  int transfer_count() const { return 24; }
-  int attack_friendly_fire() const { return 25; }
-  int base_r() const { return 26; }
-  int gained(int r) const { return base_r() + 0 * R + r; }
-  int lost(int r) const { return base_r() + 1 * R + r; }
-  int amount(int r) const { return base_r() + 2 * R + r; }
-  int damaged(int r) const { return base_r() + 3 * R + r; }
-  int chest_deposited(int r) const { return base_r() + 4 * R + r; }
-  int chest_withdrawn(int r) const { return base_r() + 5 * R + r; }
-  int transfer_self(int r) const { return base_r() + 6 * R + r; }
-  int base_g() const { return base_r() + 7 * R; }
-  int attack_hit(int g) const { return base_g() + 0 * G + g; }
-  int attack_hit_by(int g) const { return base_g() + 1 * G + g; }
-  int attack_blocked_by(int g) const { return base_g() + 2 * G + g; }
-  int transfer_to(int g, int r) const { return base_g() + 3 * G + g * R + r; }
-  int count() const { return base_g() + 3 * G + G * R; }
+  constexpr int success(int h) const { return h; }
+  constexpr int failed(int h) const { return 3 + h; }
+  constexpr int failed_any() const { return 6; }
+  constexpr int invalid() const { return 7; }
+  constexpr int invalid_variant(int v) const { return 8 + v; }
+  constexpr int swap() const { return 17; }
+  constexpr int frozen_ticks() const { return 18; }
+  constexpr int frozen_ticks_group() const { return 19; }
+  constexpr int max_steps_without_motion() const { return 20; }
+  constexpr int diversity() const { return 21; }
+  constexpr int damage_triggered() const { return 22; }
+  constexpr int damage_items_lost() const { return 23; }
+  constexpr int transfer_count() const { return 24; }
+  constexpr int attack_friendly_fire() const { return 25; }
+  constexpr int base_r() const { return 26; }
+  constexpr int gained(int r) const { return base_r() + 0 * R + r; }
+  constexpr int lost(int r) const { return base_r() + 1 * R + r; }
+  constexpr int amount(int r) const { return base_r() + 2 * R + r; }
+  constexpr int damaged(int r) const { return base_r() + 3 * R + r; }
+  constexpr int chest_deposited(int r) const { return base_r() + 4 * R + r; }
+  constexpr int chest_withdrawn(int r) const { return base_r() + 5 * R + r; }
+  constexpr int transfer_self(int r) const { return base_r() + 6 * R + r; }
+  constexpr int base_g() const { return base_r() + 7 * R; }
+  constexpr int attack_hit(int g) const { return base_g() + 0 * G + g; }
+  constexpr int attack_hit_by(int g) const { return base_g() + 1 * G + g; }
+  constexpr int attack_blocked_by(int g) const { return base_g() + 2 * G + g; }
+  constexpr int transfer_to(int g, int r) const { return base_g() + 3 * G + g * R + r; }
+  constexpr int count() const { return base_g() + 3 * G + G * R; }
 };
 struct MgGameSlots {
   int R, C;  // C = number of map cell codes (objects.<cell name>)
-  int tokens_written() const { return 0; }
-  int tokens_dropped() const { return 1; }
-  int tokens_free_space() const { return 2; }
-  int objects(int code) const { return 3 + (code - 1); }
-  int base_r() const { return 3 + C; }
-  int assembler_created(int r) const { return base_r() + 0 * R + r; }
-  int chest_deposited(int r) const { return base_r() + 1 * R + r; }
-  int chest_withdrawn(int r) const { return base_r() + 2 * R + r; }
-  int chest_amount(int r) const { return base_r() + 3 * R + r; }
-  int count() const { return base_r() + 4 * R; }
+  constexpr int tokens_written() const { return 0; }
+  constexpr int tokens_dropped() const { return 1; }
+  constexpr int tokens_free_space() const { return 2; }
+  constexpr int objects(int code) const { return 3 + (code - 1); }
+  constexpr int base_r() const { return 3 + C; }
+  constexpr int assembler_created(int r) const { return base_r() + 0 * R + r; }
+  constexpr int chest_deposited(int r) const { return base_r() + 1 * R + r; }
+  constexpr int chest_withdrawn(int r) const { return base_r() + 2 * R + r; }
+  constexpr int chest_amount(int r) const { return base_r() + 3 * R + r; }
+  constexpr int count() const { return base_r() + 4 * R; }
 };
 
 struct MgKV {

@@ -1,0 +1,945 @@
+// mg_sim.h -- device-side simulation logic of the MettaGrid step path (included by mettagrid_hip.hip).
+//
+// One workgroup owns one environment.  All mutable per-env state (agent records, assembler records, the
+// occupancy grid, per-step stat deltas) lives in LDS for the duration of a step; thread 0 resolves the actions
+// in the reference's shuffled sequential order (exact by construction), then all waves encode observations.
+//
+// Every function cites the reference code whose result it must reproduce bit for bit
+// (paths relative to packages/mettagrid/cpp/).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "mg_device_cfg.h"
+
+#define MG_KIND_SHIFT 13
+#define MG_IDX_MASK 0x1FFF
+#define MG_CELL(kind, idx) ((uint16_t)(((kind) << MG_KIND_SHIFT) | (idx)))
+
+struct __align__(16) DAgent {  // 80 bytes; one per agent, [E][A] in HBM, staged in LDS during a step
+  uint16_t r, c, prev_r, prev_c;
+  int16_t frozen;
+  uint8_t vibe, group;
+  uint32_t swm;      // steps_without_motion (agent.hpp:39)
+  float cur_reward;  // current_stat_reward (agent.hpp:36)
+  uint32_t max_swm;  // mirror of stat status.max_steps_without_motion
+  uint16_t amt[MGD_MAX_R];
+  uint8_t order[MGD_MAX_R];  // unordered_map iteration order of the inventory
+  uint8_t n_items, nb, next_resize, diversity;
+  uint16_t presence, pad;
+};
+static_assert(sizeof(DAgent) == 80, "DAgent layout");
+
+struct __align__(16) DAsm {  // assembler.hpp:245-259
+  uint32_t cooldown_end, cooldown_duration, uses_count, clipped;
+};
+
+struct __align__(16) DEnv {
+  uint32_t step, mt_idx, seed, map_id;
+  uint32_t episodes, early_reset, done, error;
+};
+
+struct Ctx {
+  const int* __restrict__ dc;
+  uint16_t* grid;
+  DAgent* ag;
+  DAsm* as;
+  const int4* __restrict__ asm_info;  // per map: (r, c, cfg, obj_id)
+  int* sd;                            // [A][SA] agent stat deltas of this step
+  int* gd;                            // [SG] game stat deltas of this step
+  uint32_t* dirty_amt;                // [A] bit r: <r>.amount was set this step
+  uint32_t* dirty_misc;               // [A] bit0 diversity, bit1 max_steps_without_motion
+  int H, W, A, NA, R, SA, SG, NG;
+  uint32_t step;
+  int asm_dirty;
+  MgAgentSlots AS;
+  MgGameSlots GS;
+};
+
+// ---- small list helpers over the dcfg stream ----------------------------------------------------------------
+__device__ __forceinline__ int L_n(const int* dc, int off) { return dc[off]; }
+__device__ __forceinline__ int L_at(const int* dc, int off, int i) { return dc[off + 1 + i]; }
+__device__ __forceinline__ int KV_k(const int* dc, int off, int i) { return dc[off + 1 + 2 * i]; }
+__device__ __forceinline__ int KV_v(const int* dc, int off, int i) { return dc[off + 2 + 2 * i]; }
+__device__ __forceinline__ const int* group_rec(const int* dc, int g) { return dc + dc[dc[DC_OFF_GROUPS] + g]; }
+__device__ __forceinline__ const int* asm_rec(const int* dc, int a) { return dc + dc[dc[DC_OFF_ASMS] + a]; }
+__device__ __forceinline__ const int* wall_rec(const int* dc, int w) { return dc + dc[dc[DC_OFF_WALLS] + w]; }
+
+// ---- inventory: unordered_map<uint8,uint16> order emulation (hashtable.h:1888-1912) -------
+__device__ inline int mg_next_bkt(DAgent* a, int n) {
+  const int fast[14] = {2, 2, 2, 3, 5, 5, 7, 7, 11, 11, 11, 11, 13, 13};
+  if (n < 14) {
+    if (n == 0) return 1;
+    a->next_resize = (uint8_t)fast[n];
+    return fast[n];
+  }
+  const int primes[10] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
+  for (int i = 0; i < 10; i++)
+    if (primes[i] >= n) {
+      a->next_resize = (uint8_t)primes[i];
+      return primes[i];
+    }
+  a->next_resize = 59;
+  return 59;
+}
+__device__ inline void mg_insert_node(DAgent* a, int k) {
+  int nb = a->nb, b = k % nb, n = a->n_items, pos = 0;
+  bool found = false;
+  for (int i = 0; i < n; i++)
+    if (a->order[i] % nb == b) {
+      pos = i;
+      found = true;
+      break;
+    }
+  if (!found) pos = 0;
+  for (int i = n; i > pos; i--) a->order[i] = a->order[i - 1];
+  a->order[pos] = (uint8_t)k;
+  a->n_items = (uint8_t)(n + 1);
+}
+__device__ inline void mg_rehash(DAgent* a, int m) {
+  uint8_t old[MGD_MAX_R];
+  int n = a->n_items;
+  for (int i = 0; i < n; i++) old[i] = a->order[i];
+  a->n_items = 0;
+  a->nb = (uint8_t)m;
+  for (int i = 0; i < n; i++) mg_insert_node(a, old[i]);
+}
+__device__ inline void mg_map_insert(DAgent* a, int k) {  // operator[] on an absent key
+  int n_elt = a->n_items;
+  if (n_elt + 1 > a->next_resize) {
+    int min_bkts = max(n_elt + 1, a->next_resize ? 0 : 11);
+    if (min_bkts >= a->nb)
+      mg_rehash(a, mg_next_bkt(a, max(min_bkts + 1, a->nb * 2)));
+    else
+      a->next_resize = a->nb;
+  }
+  mg_insert_node(a, k);
+}
+__device__ inline void mg_map_erase(DAgent* a, int k) {
+  int n = a->n_items, pos = -1;
+  for (int i = 0; i < n; i++)
+    if (a->order[i] == k) {
+      pos = i;
+      break;
+    }
+  if (pos < 0) return;
+  for (int i = pos; i < n - 1; i++) a->order[i] = a->order[i + 1];
+  a->n_items = (uint8_t)(n - 1);
+}
+
+// SharedInventoryLimit::effective_limit (inventory.hpp:21-33)
+__device__ inline int mg_effective_limit(const int* dc, const int* gr, const DAgent* a, int li) {
+  int base = dc[gr[GR_OFF_LIMITS] + 2 * li] & 0xFFFF;
+  int eff = base;
+  if (gr[GR_HAS_MODIFIERS]) {
+    int mo = dc[gr[GR_OFF_LIMITS] + 2 * li + 1];
+    int n = L_n(dc, mo);
+    for (int i = 0; i < n; i++) eff += (int)a->amt[KV_k(dc, mo, i)] * (KV_v(dc, mo, i) & 0xFFFF);
+  }
+  eff = eff < 0 ? 0 : (eff > 65535 ? 65535 : eff);
+  return eff;
+}
+// SharedInventoryLimit::amount == sum of the amounts of the resources mapped to the limit (mod 2^16)
+__device__ inline int mg_limit_sum(const int* dc, const int* gr, const DAgent* a, int li, int R) {
+  int s = 0;
+  const int* lo = dc + gr[GR_OFF_LIMIT_OF];
+  for (int r = 0; r < R; r++)
+    if (lo[r] == li) s += a->amt[r];
+  return s & 0xFFFF;
+}
+// Inventory::free_space (inventory.cpp:96-108)
+__device__ inline int mg_free_space(const Ctx& cx, const DAgent* a, int item) {
+  const int* gr = group_rec(cx.dc, a->group);
+  int li = cx.dc[gr[GR_OFF_LIMIT_OF] + item];
+  if (li < 0) return (65535 - a->amt[item]) & 0xFFFF;
+  int used = mg_limit_sum(cx.dc, gr, a, li, cx.R), eff = mg_effective_limit(cx.dc, gr, a, li);
+  return eff > used ? eff - used : 0;
+}
+
+// Agent::on_inventory_change (agent.cpp:74-101)
+__device__ inline void mg_on_change(Ctx& cx, int ai, int item, int delta) {
+  DAgent* a = &cx.ag[ai];
+  int* sd = cx.sd + ai * cx.SA;
+  if (delta > 0)
+    sd[cx.AS.gained(item)] += delta;
+  else
+    sd[cx.AS.lost(item)] += -delta;
+  cx.dirty_amt[ai] |= (1u << item);
+  const int* gr = group_rec(cx.dc, a->group);
+  if (gr[GR_DIVERSITY_MASK] & (1 << item)) {
+    bool had = (a->presence >> item) & 1, has = a->amt[item] > 0;
+    if (had != has) {
+      a->presence = (uint16_t)(a->presence ^ (1u << item));
+      a->diversity = (uint8_t)(a->diversity + (has ? 1 : -1));
+      cx.dirty_misc[ai] |= 1u;
+    }
+  }
+}
+
+template <int D>
+__device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, bool ignore_limits);
+
+// Inventory::enforce_all_limits (inventory.cpp:126-158); nesting bounded at depth 3.
+template <int D>
+__device__ void mg_enforce_limits(Ctx& cx, int ai) {
+  DAgent* a = &cx.ag[ai];
+  const int* dc = cx.dc;
+  const int* gr = group_rec(dc, a->group);
+  int nl = gr[GR_N_LIMITS], oo = gr[GR_OFF_LIMITS_ORDER], no = L_n(dc, oo);
+  for (int li = 0; li < nl; li++) {
+    int excess = mg_limit_sum(dc, gr, a, li, cx.R) - mg_effective_limit(dc, gr, a, li);
+    if (excess <= 0) continue;
+    for (int i = 0; i < no; i++) {
+      if (KV_v(dc, oo, i) != li) continue;
+      int item = KV_k(dc, oo, i);
+      int to_drop = min((int)a->amt[item], excess);
+      if (to_drop > 0) {
+        if constexpr (D < 3) mg_inv_update<D + 1>(cx, ai, item, -to_drop, false);
+        excess = mg_limit_sum(dc, gr, a, li, cx.R) - mg_effective_limit(dc, gr, a, li);
+      }
+      if (excess <= 0) break;
+    }
+  }
+}
+
+// Inventory::update (inventory.cpp:37-85)
+template <int D>
+__device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, bool ignore_limits) {
+  DAgent* a = &cx.ag[ai];
+  const int* dc = cx.dc;
+  const int* gr = group_rec(dc, a->group);
+  int initial = a->amt[item];
+  if (initial == 0) mg_map_insert(a, item);
+  int new_amount = initial + attempted_delta;
+  int mx = 65535;
+  int li = dc[gr[GR_OFF_LIMIT_OF] + item];
+  if (!ignore_limits && li >= 0) {
+    int eff = mg_effective_limit(dc, gr, a, li);
+    int used_by_others = mg_limit_sum(dc, gr, a, li, cx.R) - initial;
+    if (used_by_others < 0) used_by_others = 0;
+    int max_int = eff - used_by_others;
+    if (max_int < 0) max_int = 0;
+    mx = max_int & 0xFFFF;
+  }
+  int clamped = (new_amount < 0) ? 0 : ((mx < new_amount) ? mx : new_amount);
+  clamped &= 0xFFFF;
+  a->amt[item] = (uint16_t)clamped;
+  if (clamped == 0) mg_map_erase(a, item);
+  int cd = clamped - initial;
+  if (cd != 0) mg_on_change(cx, ai, item, cd);
+  if (cd < 0 && dc[gr[GR_OFF_MODIFIER] + item]) mg_enforce_limits<D>(cx, ai);
+  return cd;
+}
+__device__ inline int inv_update(Ctx& cx, int ai, int item, int delta, bool ignore = false) {
+  return mg_inv_update<0>(cx, ai, item, delta, ignore);
+}
+
+// HasInventory::shared_update (has_inventory.cpp:7-73) over agent inventories
+__device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item, int delta) {
+  if (n == 0) return 0;
+  int consider[8], next[8];
+  int n_consider = 0, n_next = n;
+  for (int i = 0; i < n; i++) next[i] = list[i];
+  int delta_remaining = delta, num_remaining = n;
+  int per = delta_remaining / num_remaining;
+  do {
+    n_consider = n_next;
+    for (int i = 0; i < n_next; i++) consider[i] = next[i];
+    n_next = 0;
+    for (int i = 0; i < n_consider; i++) {
+      int ai = consider[i];
+      bool now;
+      if (delta_remaining > 0)
+        now = mg_free_space(cx, &cx.ag[ai], item) <= per;
+      else
+        now = (int)cx.ag[ai].amt[item] <= -per;
+      if (now) {
+        delta_remaining -= inv_update(cx, ai, item, per);
+        num_remaining--;
+        if (num_remaining > 0) per = delta_remaining / num_remaining;
+      } else {
+        next[n_next++] = ai;
+      }
+    }
+  } while (n_consider != n_next);
+  if (num_remaining == 0) return delta - delta_remaining;
+  for (int i = n_consider - 1; i >= 0; i--) {
+    int d = delta_remaining / (i + 1);
+    delta_remaining -= inv_update(cx, consider[i], item, d);
+  }
+  return delta - delta_remaining;
+}
+
+// ---- assembler ---------------------------------------------------------------------------------------------
+// Assembler::get_current_protocol (assembler.hpp:353-408).  Returns the protocol record offset or -1.
+__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, int H, int W, int ar,
+                                          int ac, int cfg, bool clipped) {
+  uint8_t vibes[8];
+  int nv = 0, n_agents = 0;
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) {
+      if (i == 0 && j == 0) continue;
+      int rr = ar + i, cc = ac + j;
+      if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
+      uint16_t cv = grid[rr * W + cc];
+      if ((cv >> MG_KIND_SHIFT) == MG_CELL_AGENT) {
+        n_agents++;
+        uint8_t v = ag[cv & MG_IDX_MASK].vibe;
+        if (v != 0) {  // insertion sort (std::sort of the vibe vector)
+          int p = nv++;
+          while (p > 0 && vibes[p - 1] > v) {
+            vibes[p] = vibes[p - 1];
+            p--;
+          }
+          vibes[p] = v;
+        }
+      }
+    }
+  if (clipped) return -1;  // unclip protocols only come from a Clipper (out of scope)
+  unsigned long long key = 0;
+  for (int i = 0; i < nv; i++) key = (key << 8) | vibes[i];
+  const int* rec = asm_rec(dc, cfg);
+  int nk = rec[AR_N_KEYS], ok = rec[AR_OFF_KEYS], pt = rec[AR_OFF_PTABLE];
+  for (int attempt = 0; attempt < 2; attempt++) {
+    unsigned long long k = attempt == 0 ? key : 0ull;
+    for (int q = 0; q < nk; q++) {
+      unsigned long long kk = ((unsigned long long)(uint32_t)dc[ok + 3 * q + 1] << 32) | (uint32_t)dc[ok + 3 * q];
+      if (kk != k) continue;
+      int lo = dc[ok + 3 * q + 2], n = L_n(dc, lo);
+      for (int i = 0; i < n; i++) {
+        int po = dc[pt + L_at(dc, lo, i)];
+        if (dc[po + PR_MIN_AGENTS] <= n_agents) return po;
+      }
+    }
+  }
+  return -1;
+}
+
+__device__ inline int mg_kv_lookup(const int* dc, int off, int k) {
+  int n = L_n(dc, off);
+  for (int i = 0; i < n; i++)
+    if (KV_k(dc, off, i) == k) return KV_v(dc, off, i);
+  return 0;
+}
+
+// Assembler::onUse (assembler.hpp:455-526)
+__device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
+  const int* dc = cx.dc;
+  DAsm* as = &cx.as[asm_idx];
+  int4 info = cx.asm_info[asm_idx];
+  int ar = info.x, ac = info.y;
+  const int* rec = asm_rec(dc, info.z);
+  uint32_t max_uses = (uint32_t)rec[AR_MAX_USES];
+  if (max_uses > 0 && as->uses_count >= max_uses) return false;
+  uint32_t remaining = as->cooldown_end <= cx.step ? 0 : as->cooldown_end - cx.step;
+  bool partial = rec[AR_ALLOW_PARTIAL] != 0;
+  if (remaining > 0 && !partial) return false;
+  int po = mg_current_protocol(dc, cx.grid, cx.ag, cx.H, cx.W, ar, ac, info.z, as->clipped != 0);
+  if (po < 0) return false;
+  // protocol_to_use as (item, amount) lists
+  int in_k[MGD_MAX_R], in_v[MGD_MAX_R], out_k[MGD_MAX_R], out_v[MGD_MAX_R];
+  int n_in, n_out;
+  int oin = dc[po + PR_OFF_IN], oout = dc[po + PR_OFF_OUT];
+  bool orig_pos_out = false;
+  {
+    int n = L_n(dc, oout);
+    for (int i = 0; i < n; i++)
+      if (KV_v(dc, oout, i) > 0) orig_pos_out = true;
+  }
+  if (remaining > 0 && partial) {
+    uint32_t duration = as->cooldown_duration, elapsed = duration - remaining;
+    int ois = dc[po + PR_OFF_IN_S], oos = dc[po + PR_OFF_OUT_S];
+    n_in = L_n(dc, ois);
+    for (int i = 0; i < n_in; i++) {
+      int k = L_at(dc, ois, i);
+      in_k[i] = k;
+      in_v[i] = (int)((((uint32_t)mg_kv_lookup(dc, oin, k) * elapsed + duration - 1) / duration) & 0xFFFF);
+    }
+    n_out = L_n(dc, oos);
+    bool pos_out = false;
+    for (int i = 0; i < n_out; i++) {
+      int k = L_at(dc, oos, i);
+      out_k[i] = k;
+      out_v[i] = (int)((((uint32_t)mg_kv_lookup(dc, oout, k) * elapsed) / duration) & 0xFFFF);
+      if (out_v[i] > 0) pos_out = true;
+    }
+    if (!pos_out && orig_pos_out && !as->clipped) return false;
+  } else {
+    n_in = L_n(dc, oin);
+    for (int i = 0; i < n_in; i++) {
+      in_k[i] = KV_k(dc, oin, i);
+      in_v[i] = KV_v(dc, oin, i);
+    }
+    n_out = L_n(dc, oout);
+    for (int i = 0; i < n_out; i++) {
+      out_k[i] = KV_k(dc, oout, i);
+      out_v[i] = KV_v(dc, oout, i);
+    }
+  }
+  // surrounding agents, rotated to start at the actor (assembler.hpp:48-92)
+  const DAgent* actor = &cx.ag[ai_actor];
+  int pr[8], pc[8], np = 0, start = -1;
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) {
+      if (i == 0 && j == 0) continue;
+      int rr = ar + i, cc = ac + j;
+      if (rr < 0 || cc < 0 || rr >= cx.H || cc >= cx.W) continue;
+      if (rr == actor->r && cc == actor->c && start < 0) start = np;
+      pr[np] = rr;
+      pc[np] = cc;
+      np++;
+    }
+  if (start < 0) return false;  // reference throws; cannot happen for a move into the assembler
+  int near[8], nn = 0;
+  for (int q = 0; q < np; q++) {
+    int p = (start + q) % np;
+    uint16_t cv = cx.grid[pr[p] * cx.W + pc[p]];
+    if ((cv >> MG_KIND_SHIFT) == MG_CELL_AGENT) near[nn++] = cv & MG_IDX_MASK;
+  }
+  // can_afford_protocol: uint16 totals (assembler.hpp:124-137)
+  for (int i = 0; i < n_in; i++) {
+    int total = 0;
+    for (int q = 0; q < nn; q++) total = (total + cx.ag[near[q]].amt[in_k[i]]) & 0xFFFF;
+    if (total < (in_v[i] & 0xFFFF)) return false;
+  }
+  // get_output_inventories (assembler.hpp:198-223)
+  int outs[8], no = 0;
+  int ov = dc[po + PR_OFF_VIBES], nvib = L_n(dc, ov);
+  if (nvib <= 1) {
+    outs[no++] = ai_actor;
+  } else {
+    int cnt[8];  // remaining required count per distinct position in the vibes list
+    for (int i = 0; i < nvib && i < 8; i++) cnt[i] = 1;
+    for (int q = 0; q < nn; q++) {
+      uint8_t v = cx.ag[near[q]].vibe;
+      if (v == 0) continue;
+      int slot = -1;
+      for (int i = 0; i < nvib && i < 8; i++)
+        if (L_at(dc, ov, i) == v && cnt[i] > 0) {
+          slot = i;
+          break;
+        }
+      if (slot < 0) continue;
+      cnt[slot] = 0;
+      outs[no++] = near[q];
+      if (no >= nvib) break;
+    }
+    if (no == 0) outs[no++] = ai_actor;
+  }
+  // can_receive_output (assembler.hpp:143-171)
+  {
+    bool pos_out = false;
+    for (int i = 0; i < n_out; i++)
+      if (out_v[i] > 0) pos_out = true;
+    bool ok = true;
+    if (pos_out) {
+      ok = false;
+      for (int i = 0; i < n_out && !ok; i++)
+        if (out_v[i] > 0) {
+          int total_free = 0;
+          for (int q = 0; q < no; q++) total_free = (total_free + mg_free_space(cx, &cx.ag[outs[q]], out_k[i])) & 0xFFFF;
+          if (total_free >= 1) ok = true;
+        }
+    }
+    if (!ok && !as->clipped) return false;
+  }
+  for (int i = 0; i < n_in; i++) mg_shared_update(cx, near, nn, in_k[i], -in_v[i]);
+  for (int i = 0; i < n_out; i++) {
+    int distributed = mg_shared_update(cx, outs, no, out_k[i], out_v[i]);
+    if (distributed > 0) cx.gd[cx.GS.assembler_created(out_k[i])] += distributed;
+  }
+  as->cooldown_duration = (uint32_t)dc[po + PR_COOLDOWN];
+  as->cooldown_end = cx.step + as->cooldown_duration;
+  if (as->clipped)
+    as->clipped = 0;
+  else
+    as->uses_count++;
+  cx.asm_dirty = 1;
+  return true;
+}
+
+// ---- attack / transfer (attack.hpp:93-253, transfer.hpp:72-150) ----------------------------------------------
+__device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
+  const int* dc = cx.dc;
+  if ((target_cell >> MG_KIND_SHIFT) != MG_CELL_AGENT) return false;
+  int ti = target_cell & MG_IDX_MASK;
+  DAgent* actor = &cx.ag[ai];
+  DAgent* target = &cx.ag[ti];
+  if (target->frozen > 0) return false;
+  int oc = dc[DC_OFF_ATK_CONSUMED], nc = L_n(dc, oc);
+  for (int i = 0; i < nc; i++)
+    if ((int)actor->amt[KV_k(dc, oc, i)] < (KV_v(dc, oc, i) & 0xFFFF)) return false;
+  int ag = group_rec(dc, actor->group)[GR_NAME_IDX], tg = group_rec(dc, target->group)[GR_NAME_IDX];
+  int* sda = cx.sd + ai * cx.SA;
+  bool blocked = false;
+  if (dc[DC_HAS_DEFENSE]) {
+    int weapon = 0, armor = 0;
+    int ow = dc[DC_OFF_ATK_WEAPON], nw = L_n(dc, ow);
+    for (int i = 0; i < nw; i++) weapon += (int)actor->amt[KV_k(dc, ow, i)] * (KV_v(dc, ow, i) & 0xFFFF);
+    int oa = dc[DC_OFF_ATK_ARMOR], na = L_n(dc, oa);
+    for (int i = 0; i < na; i++) {
+      int item = KV_k(dc, oa, i);
+      int amount = target->amt[item];
+      bool vibing = target->vibe != 0 && (int)target->vibe < dc[DC_N_VIBES] && item < cx.R &&
+                    dc[dc[DC_OFF_VIBE_RESOURCE] + target->vibe] == item;
+      if (vibing) amount += dc[dc[DC_OFF_ATK_VIBE_BONUS] + target->vibe];
+      armor += amount * (KV_v(dc, oa, i) & 0xFFFF);
+    }
+    int bonus = max(weapon - armor, 0);
+    int od = dc[DC_OFF_ATK_DEFENSE], nd = L_n(dc, od);
+    bool can = true;
+    for (int i = 0; i < nd; i++) {
+      int required = (KV_v(dc, od, i) & 0xFFFF) + bonus;
+      if ((int)target->amt[KV_k(dc, od, i)] < (required & 0xFFFF)) {
+        can = false;
+        break;
+      }
+    }
+    if (can) {
+      // _consume_defense_resources recomputes the powers before consuming; nothing changed in between.
+      for (int i = 0; i < nd; i++) inv_update(cx, ti, KV_k(dc, od, i), -((KV_v(dc, od, i) & 0xFFFF) + bonus));
+      sda[cx.AS.attack_blocked_by(tg)] += 1;
+      blocked = true;
+    }
+  }
+  if (!blocked) {
+    if (dc[DC_ATK_FREEZE] > 0) target->frozen = (int16_t)dc[DC_ATK_FREEZE];
+    int o1 = dc[DC_OFF_ATK_ACTOR], n1 = L_n(dc, o1);
+    for (int i = 0; i < n1; i++) inv_update(cx, ai, KV_k(dc, o1, i), KV_v(dc, o1, i));
+    int o2 = dc[DC_OFF_ATK_TARGET], n2 = L_n(dc, o2);
+    for (int i = 0; i < n2; i++) inv_update(cx, ti, KV_k(dc, o2, i), KV_v(dc, o2, i));
+    int ol = dc[DC_OFF_ATK_LOOT], nl = L_n(dc, ol);
+    for (int i = 0; i < nl; i++) {
+      int item = L_at(dc, ol, i);
+      int amount = target->amt[item];
+      if (amount > 0) {
+        int stolen = inv_update(cx, ai, item, amount);
+        inv_update(cx, ti, item, -stolen);
+      }
+    }
+    if (ag == tg) {
+      sda[cx.AS.attack_friendly_fire()] += 1;
+    } else {
+      sda[cx.AS.attack_hit(tg)] += 1;
+      cx.sd[ti * cx.SA + cx.AS.attack_hit_by(ag)] += 1;
+    }
+  }
+  for (int i = 0; i < nc; i++)
+    if (KV_v(dc, oc, i) > 0) inv_update(cx, ai, KV_k(dc, oc, i), -(KV_v(dc, oc, i) & 0xFFFF));
+  return true;
+}
+
+__device__ inline bool mg_try_transfer(Ctx& cx, int ai, uint16_t target_cell) {
+  const int* dc = cx.dc;
+  DAgent* actor = &cx.ag[ai];
+  int orq = dc[DC_OFF_XFER_REQUIRED], nrq = L_n(dc, orq);
+  for (int i = 0; i < nrq; i++)
+    if ((int)actor->amt[KV_k(dc, orq, i)] < (KV_v(dc, orq, i) & 0xFFFF)) return false;
+  if ((target_cell >> MG_KIND_SHIFT) != MG_CELL_AGENT) return false;
+  int ti = target_cell & MG_IDX_MASK;
+  DAgent* target = &cx.ag[ti];
+  if (target->frozen > 0) return false;
+  int oe = dc[DC_OFF_XFER_EFFECTS], ne = dc[oe];
+  int oa = -1, ot = -1;
+  for (int i = 0; i < ne; i++)
+    if (dc[oe + 1 + 3 * i] == actor->vibe) {
+      oa = dc[oe + 2 + 3 * i];
+      ot = dc[oe + 3 + 3 * i];
+    }
+  if (oa < 0) return false;
+  int tg = group_rec(dc, target->group)[GR_NAME_IDX];
+  int na = L_n(dc, oa), nt = L_n(dc, ot);
+  for (int i = 0; i < na; i++) {
+    int d = KV_v(dc, oa, i);
+    if (d < 0 && (int)actor->amt[KV_k(dc, oa, i)] < -d) return false;
+  }
+  for (int i = 0; i < nt; i++) {
+    int d = KV_v(dc, ot, i);
+    if (d < 0 && (int)target->amt[KV_k(dc, ot, i)] < -d) return false;
+  }
+  for (int i = 0; i < na; i++) {
+    int d = KV_v(dc, oa, i);
+    if (d > 0 && d > mg_free_space(cx, actor, KV_k(dc, oa, i))) return false;
+  }
+  for (int i = 0; i < nt; i++) {
+    int d = KV_v(dc, ot, i);
+    if (d > 0 && d > mg_free_space(cx, target, KV_k(dc, ot, i))) return false;
+  }
+  int* sda = cx.sd + ai * cx.SA;
+  for (int i = 0; i < na; i++) {
+    int d = KV_v(dc, oa, i), item = KV_k(dc, oa, i);
+    if (d != 0) {
+      int actual = inv_update(cx, ai, item, d);
+      if (actual != 0) sda[cx.AS.transfer_self(item)] += actual;
+    }
+  }
+  for (int i = 0; i < nt; i++) {
+    int d = KV_v(dc, ot, i), item = KV_k(dc, ot, i);
+    if (d != 0) {
+      int actual = inv_update(cx, ti, item, d);
+      if (actual != 0) sda[cx.AS.transfer_to(tg, item)] += actual;
+    }
+  }
+  sda[cx.AS.transfer_count()] += 1;
+  return true;
+}
+
+// Move::_handle_action (move.hpp:74-141)
+__device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
+  const int DX[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+  const int DY[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
+  DAgent* actor = &cx.ag[ai];
+  int tr = (int)actor->r + DY[orientation], tc = (int)actor->c + DX[orientation];
+  if (tr < 0 || tc < 0 || tr >= cx.H || tc >= cx.W) return false;
+  uint16_t target = cx.grid[tr * cx.W + tc];
+  int vh = cx.dc[cx.dc[DC_OFF_VIBE_HANDLER] + actor->vibe];
+  if (vh == MG_VH_ATTACK) {
+    if (mg_try_attack(cx, ai, target)) return true;
+  } else if (vh == MG_VH_TRANSFER) {
+    if (mg_try_transfer(cx, ai, target)) return true;
+  }
+  int kind = target >> MG_KIND_SHIFT;
+  if (kind == MG_CELL_EMPTY) {
+    cx.grid[tr * cx.W + tc] = MG_CELL(MG_CELL_AGENT, ai);
+    cx.grid[(int)actor->r * cx.W + actor->c] = 0;
+    actor->r = (uint16_t)tr;
+    actor->c = (uint16_t)tc;
+    return true;
+  }
+  if (kind == MG_CELL_AGENT) {
+    int ti = target & MG_IDX_MASK;
+    DAgent* ta = &cx.ag[ti];
+    if (ta->frozen > 0) {
+      cx.grid[(int)actor->r * cx.W + actor->c] = MG_CELL(MG_CELL_AGENT, ti);
+      cx.grid[tr * cx.W + tc] = MG_CELL(MG_CELL_AGENT, ai);
+      ta->r = actor->r;
+      ta->c = actor->c;
+      actor->r = (uint16_t)tr;
+      actor->c = (uint16_t)tc;
+      cx.sd[ai * cx.SA + cx.AS.swap()] += 1;
+      return true;
+    }
+    return false;  // Agent::onUse (agent.cpp:179-185)
+  }
+  if (kind == MG_CELL_ASSEMBLER) return mg_assembler_use(cx, ai, target & MG_IDX_MASK);
+  return false;  // walls are not Usable
+}
+
+// ActionHandler::handle_action (action_handler.hpp:99-153)
+__device__ inline bool mg_handle_action(Ctx& cx, int ai, int kind, int arg) {
+  DAgent* actor = &cx.ag[ai];
+  int* sda = cx.sd + ai * cx.SA;
+  const int* dc = cx.dc;
+  if (actor->frozen != 0) {
+    sda[cx.AS.frozen_ticks()] += 1;
+    sda[cx.AS.frozen_ticks_group()] += 1;
+    if (actor->frozen > 0) actor->frozen -= 1;
+    return false;
+  }
+  int orq = dc[DC_OFF_HANDLERS + 2 * kind], nrq = L_n(dc, orq);
+  bool has = true;
+  for (int i = 0; i < nrq; i++)
+    if ((int)actor->amt[KV_k(dc, orq, i)] < (KV_v(dc, orq, i) & 0xFFFF)) {
+      has = false;
+      break;
+    }
+  bool success = false;
+  if (has) {
+    if (kind == MG_ACT_NOOP)
+      success = true;
+    else if (kind == MG_ACT_MOVE)
+      success = mg_do_move(cx, ai, arg);
+    else {
+      actor->vibe = (uint8_t)arg;
+      success = true;
+    }
+  }
+  if (actor->r == actor->prev_r && actor->c == actor->prev_c) {
+    actor->swm += 1;
+    if ((float)actor->swm > (float)actor->max_swm) {  // both exact in f32 below 2^24; compared as floats upstream
+      actor->max_swm = actor->swm;
+      cx.dirty_misc[ai] |= 2u;
+    }
+  } else {
+    actor->swm = 0;
+  }
+  actor->prev_r = actor->r;
+  actor->prev_c = actor->c;
+  if (success) {
+    sda[cx.AS.success(kind)] += 1;
+    int oc = dc[DC_OFF_HANDLERS + 2 * kind + 1], nc = L_n(dc, oc);
+    for (int i = 0; i < nc; i++)
+      if (KV_v(dc, oc, i) > 0) inv_update(cx, ai, KV_k(dc, oc, i), -(KV_v(dc, oc, i) & 0xFFFF));
+  } else {
+    sda[cx.AS.failed(kind)] += 1;
+    sda[cx.AS.failed_any()] += 1;
+  }
+  return success;
+}
+
+// ---- RNG: std::mt19937 tempering + libstdc++ Lemire bounded draw ---------------------------
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {  // new = c ^ twist(a, b)
+  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+struct RngWin {  // window of pre-tempered outputs staged in LDS
+  const uint32_t* win;
+  int n, used;
+  int overflow;
+  __device__ uint32_t next() {
+    if (used >= n) {
+      overflow = 1;
+      return 0;
+    }
+    return win[used++];
+  }
+  __device__ uint32_t bounded(uint32_t range) {  // uniform_int_dist.h:258-269
+    unsigned long long product = (unsigned long long)next() * range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+      uint32_t threshold = (0u - range) % range;
+      while (low < threshold && !overflow) {
+        product = (unsigned long long)next() * range;
+        low = (uint32_t)product;
+      }
+    }
+    return (uint32_t)(product >> 32);
+  }
+};
+// std::shuffle of iota(n) (stl_algo.h:3726-3792)
+__device__ inline void mg_shuffle(uint16_t* v, int n, RngWin& g) {
+  for (int i = 0; i < n; i++) v[i] = (uint16_t)i;
+  if (n == 0) return;
+  // (0xFFFFFFFF / n) >= n holds for every n <= 65535
+  int i = 1;
+  if ((n & 1) == 0) {
+    uint32_t j = g.bounded(2);
+    uint16_t t = v[1];
+    v[1] = v[j];
+    v[j] = t;
+    i = 2;
+  }
+  while (i != n) {
+    uint32_t s = (uint32_t)i + 1;
+    uint32_t x = g.bounded(s * (s + 1));
+    uint32_t a = x / (s + 1), b = x % (s + 1);
+    uint16_t t = v[i];
+    v[i] = v[a];
+    v[a] = t;
+    t = v[i + 1];
+    v[i + 1] = v[b];
+    v[b] = t;
+    i += 2;
+  }
+}
+
+// ---- observation tokens --------------------------------------------------------------------------------------
+// Number of tokens of inventory item with `amount` (observation_encoder.hpp:165-180)
+__device__ __forceinline__ int mg_inv_ntok(int amount, int base, int n_inv_tokens) {
+  int n = 1;
+  unsigned rem = (unsigned)amount / (unsigned)base;
+  for (int p = 1; p < n_inv_tokens && rem > 0; p++) {
+    n++;
+    rem /= (unsigned)base;
+  }
+  return n;
+}
+
+struct TokOut {  // writes (loc, feature, value) triples into an LDS row, dropping tokens past the budget
+  uint8_t* row;
+  int T, pos;
+  uint8_t loc;
+  __device__ __forceinline__ void put(int f, int v) {
+    if (pos < T) {
+      row[pos * 3 + 0] = loc;
+      row[pos * 3 + 1] = (uint8_t)f;
+      row[pos * 3 + 2] = (uint8_t)v;
+    }
+    pos++;
+  }
+};
+
+// Count (emit == false) or write (emit == true) the tokens of the object in cell `cv`
+// (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578).
+template <bool EMIT>
+__device__ inline int mg_object_tokens(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
+                                       const int4* asm_info, int H, int W, uint32_t step, uint16_t cv, TokOut* out) {
+  int kind = cv >> MG_KIND_SHIFT, idx = cv & MG_IDX_MASK;
+  int n = 0;
+  const int f_tag = dc[DC_FID0 + MG_F_TAG], f_vibe = dc[DC_FID0 + MG_F_VIBE];
+  if (kind == MG_CELL_WALL) {
+    const int* rec = wall_rec(dc, idx);
+    int ot = rec[WR_OFF_TAGS], nt = L_n(dc, ot);
+    if (EMIT)
+      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
+    n += nt;
+    if (rec[WR_VIBE] != 0) {
+      if (EMIT) out->put(f_vibe, rec[WR_VIBE]);
+      n++;
+    }
+  } else if (kind == MG_CELL_AGENT) {
+    const DAgent* a = &ag[idx];
+    const int* gr = group_rec(dc, a->group);
+    int base = dc[DC_TOKEN_BASE], nit = dc[DC_N_INV_TOKENS], ofi = dc[DC_OFF_FID_INV];
+    if (EMIT) {
+      out->put(dc[DC_FID0 + MG_F_GROUP], gr[GR_GROUP_ID]);
+      out->put(dc[DC_FID0 + MG_F_FROZEN], a->frozen != 0 ? 1 : 0);
+      if (a->vibe != 0) out->put(f_vibe, a->vibe);
+    }
+    n += 2 + (a->vibe != 0 ? 1 : 0);
+    int ni = a->n_items;
+    for (int i = 0; i < ni; i++) {
+      int item = a->order[i], amount = a->amt[item];
+      if (EMIT) {
+        out->put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
+        unsigned rem = (unsigned)amount / (unsigned)base;
+        for (int p = 1; p < nit && rem > 0; p++) {
+          out->put(dc[ofi + item * nit + p], rem % (unsigned)base);
+          rem /= (unsigned)base;
+        }
+      }
+      n += mg_inv_ntok(amount, base, nit);
+    }
+    int ot = gr[GR_OFF_TAGS], nt = L_n(dc, ot);
+    if (EMIT)
+      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
+    n += nt;
+  } else if (kind == MG_CELL_ASSEMBLER) {
+    const DAsm* s = &as[idx];
+    int4 info = asm_info[idx];
+    const int* rec = asm_rec(dc, info.z);
+    uint32_t remaining = s->cooldown_end <= step ? 0 : s->cooldown_end - step;
+    if (remaining > 255u) remaining = 255u;
+    if (remaining > 0) {
+      if (EMIT) out->put(dc[DC_FID0 + MG_F_COOLDOWN], (int)remaining);
+      n++;
+    }
+    if (s->clipped) {
+      if (EMIT) out->put(dc[DC_FID0 + MG_F_CLIPPED], 1);
+      n++;
+    }
+    uint32_t max_uses = (uint32_t)rec[AR_MAX_USES];
+    if (max_uses > 0) {
+      uint32_t ru = s->uses_count < max_uses ? max_uses - s->uses_count : 0;
+      if (ru > 255u) ru = 255u;
+      if (EMIT) out->put(dc[DC_FID0 + MG_F_REMAINING_USES], (int)ru);
+      n++;
+    }
+    if (dc[DC_PROTO_OBS]) {
+      int po = mg_current_protocol(dc, grid, ag, H, W, info.x, info.y, info.z, s->clipped != 0);
+      if (po >= 0) {
+        int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
+        for (int i = 0; i < ni; i++)
+          if (KV_v(dc, oi, i) > 0) {
+            if (EMIT) out->put(dc[dc[DC_OFF_FID_IN] + KV_k(dc, oi, i)], KV_v(dc, oi, i));
+            n++;
+          }
+        int oo = dc[po + PR_OFF_OUT], no = L_n(dc, oo);
+        for (int i = 0; i < no; i++)
+          if (KV_v(dc, oo, i) > 0) {
+            if (EMIT) out->put(dc[dc[DC_OFF_FID_OUT] + KV_k(dc, oo, i)], KV_v(dc, oo, i));
+            n++;
+          }
+      }
+    }
+    int ot = rec[AR_OFF_TAGS], nt = L_n(dc, ot);
+    if (EMIT)
+      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
+    n += nt;
+    if (rec[AR_VIBE] != 0) {
+      if (EMIT) out->put(f_vibe, rec[AR_VIBE]);
+      n++;
+    }
+  }
+  return n;
+}
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  *total = __shfl(x, 63, 64);
+  return x - v;
+}
+
+// One agent's observation row, encoded by one wave into `row` (LDS, T*3 bytes, pre-filled with 0xFF).
+// MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns attempted token count.
+__device__ inline int mg_encode_agent(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
+                                      const int4* asm_info, int H, int W, uint32_t step, int ai, int action,
+                                      uint8_t* row, int lane) {
+  const DAgent* me = &ag[ai];
+  const int T = dc[DC_T], oh = dc[DC_OBS_H], ow = dc[DC_OBS_W];
+  const int hr = oh >> 1, wr = ow >> 1;
+  const int ar = me->r, ac = me->c;
+  int base = 0;
+  {
+    // global tokens + compass: a handful of tokens, written by lane 0
+    TokOut o{row, T, 0, (uint8_t)((hr << 4) | (wr & 0x0F))};
+    if (dc[DC_G_COMPLETION]) {
+      int pct = 0, ms = dc[DC_MAX_STEPS];
+      if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
+      if (lane == 0) o.put(dc[DC_FID0 + MG_F_COMPLETION], pct); else o.pos++;
+    }
+    if (dc[DC_G_LAST_ACTION]) {
+      if (lane == 0) o.put(dc[DC_FID0 + MG_F_LAST_ACTION], action); else o.pos++;
+    }
+    if (dc[DC_G_LAST_REWARD]) {
+      // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
+      if (lane == 0) o.put(dc[DC_FID0 + MG_F_LAST_REWARD], 0); else o.pos++;
+    }
+    if (dc[DC_G_GOAL]) {
+      const int* gr = group_rec(dc, me->group);
+      int og = gr[GR_OFF_GOAL], ng = L_n(dc, og);
+      for (int i = 0; i < ng; i++) {
+        if (lane == 0) o.put(dc[DC_FID0 + MG_F_GOAL], L_at(dc, og, i)); else o.pos++;
+      }
+    }
+    if (dc[DC_G_COMPASS]) {
+      int dr = H / 2 - ar, dcc = W / 2 - ac;
+      int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
+      if (sr != 0 || sc != 0) {
+        int orr = hr + sr, occ = wr + sc;
+        if (orr >= 0 && orr < oh && occ >= 0 && occ < ow) {
+          o.loc = (uint8_t)((orr << 4) | (occ & 0x0F));
+          if (lane == 0) o.put(dc[DC_FID0 + MG_F_COMPASS], 1); else o.pos++;
+        }
+      }
+    }
+    base = o.pos;
+  }
+  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN];
+  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
+  const int r_end = min(ar + hr + 1, H), c_end = min(ac + wr + 1, W);
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    int p = p0 + lane;
+    uint16_t cv = 0;
+    int r = 0, c = 0;
+    if (p < P) {
+      int packed = dc[op + p];
+      r = ar + (packed & 0xFF) - 8;
+      c = ac + ((packed >> 8) & 0xFF) - 8;
+      if (r >= r_start && r < r_end && c >= c_start && c < c_end) cv = grid[r * W + c];
+    }
+    int n = 0;
+    if (cv != 0) n = mg_object_tokens<false>(dc, grid, ag, as, asm_info, H, W, step, cv, nullptr);
+    int total;
+    int off = base + wave_excl_scan(n, lane, &total);
+    if (n > 0 && off < T) {
+      TokOut o{row, T, off, (uint8_t)(((r - ar + hr) << 4) | ((c - ac + wr) & 0x0F))};
+      mg_object_tokens<true>(dc, grid, ag, as, asm_info, H, W, step, cv, &o);
+    }
+    base += total;
+  }
+  return base;
+}

@@ -1,0 +1,92 @@
+"""ctypes binding of libmettagrid_hip.so (the C-ABI declared in include/mettagrid_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or cannot be loaded, importing a symbol from
+it raises.  The CPU restatement under oracle/ is test infrastructure and is never reachable from here.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libmettagrid_hip.so"
+_lib = None
+
+
+class MgBuffers(ct.Structure):
+    _fields_ = [
+        ("observations", ct.c_void_p),
+        ("rewards", ct.c_void_p),
+        ("terminals", ct.c_void_p),
+        ("truncations", ct.c_void_p),
+        ("actions", ct.c_void_p),
+        ("masks", ct.c_void_p),
+        ("episode_rewards", ct.c_void_p),
+        ("action_success", ct.c_void_p),
+        ("num_envs", ct.c_int32),
+        ("num_agents", ct.c_int32),
+        ("num_tokens", ct.c_int32),
+        ("num_actions", ct.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/mettagrid_hip.h declares
+_vp, _i32p, _u32p, _u8p, _f32p, _f64p = (
+    ct.c_void_p,
+    ct.POINTER(ct.c_int32),
+    ct.POINTER(ct.c_uint32),
+    ct.POINTER(ct.c_uint8),
+    ct.POINTER(ct.c_float),
+    ct.POINTER(ct.c_double),
+)
+SYMBOLS = {
+    "mg_last_error": (ct.c_char_p, []),
+    "mg_version": (ct.c_char_p, []),
+    "mg_create": (ct.c_int, [_i32p, ct.c_size_t, ct.c_int, ct.c_int, ct.POINTER(_vp)]),
+    "mg_set_maps": (ct.c_int, [_vp, _u8p, ct.c_int, ct.c_int, ct.c_int]),
+    "mg_reset": (ct.c_int, [_vp, _i32p, ct.c_int, _u32p, _i32p, _vp]),
+    "mg_step": (ct.c_int, [_vp, _vp]),
+    "mg_set_auto_reset": (ct.c_int, [_vp, ct.c_int, ct.c_int]),
+    "mg_set_early_reset": (ct.c_int, [_vp, _u32p]),
+    "mg_get_buffers": (ct.c_int, [_vp, ct.POINTER(MgBuffers)]),
+    "mg_end_episode": (ct.c_int, [_vp, ct.c_int, _vp]),
+    "mg_episode_stats": (ct.c_int, [_vp, ct.c_int, ct.c_int, _f32p, _u8p, _f32p, _u8p, _vp]),
+    "mg_stat_slots": (ct.c_int, [_vp, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]),
+    "mg_agent_state": (ct.c_int, [_vp, ct.c_int, _i32p, _vp]),
+    "mg_num_assemblers": (ct.c_int, [_vp, ct.c_int]),
+    "mg_assembler_state": (ct.c_int, [_vp, ct.c_int, _i32p, _vp]),
+    "mg_env_info": (ct.c_int, [_vp, ct.c_int, _u32p, _i32p, _u32p, _u32p, _vp]),
+    "mg_set_inventory": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _vp]),
+    "mg_finished_summary": (ct.c_int, [_vp, _f64p, ct.c_int, _vp]),
+    "mg_set_profiling": (ct.c_int, [_vp, ct.c_int]),
+    "mg_last_step_ms": (ct.c_int, [_vp, _f32p]),
+    "mg_destroy": (ct.c_int, [_vp]),
+}
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load() -> ct.CDLL:
+    """Load the HIP library (built in-tree by `__graft_entry__.build()` / metta_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise ImportError(
+            f"{_LIB_PATH} is missing: build it with `make -C metta_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "The device path has no CPU fallback."
+        )
+    L = ct.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(load().mg_last_error().decode())

@@ -182,6 +182,27 @@ struct U8Map {
   uint16_t get(uint8_t k) const { return has[k] ? val[k] : 0; }
 };
 
+// ObservationPattern (packed_coordinate.hpp:74-143): offsets by (manhattan distance, dr, dc).  The iterator walks
+// shells d = 0,1,..; within a shell dr = -d..d, and for each dr first -dc then +dc, keeping offsets inside
+// [-h/2, h/2] x [-w/2, w/2] (C++ int division) until h*w offsets were emitted.
+static std::vector<std::pair<int, int>> observation_pattern(int h, int w) {
+  std::vector<std::pair<int, int>> out;
+  int emitted = 0, max_emitted = h * w;
+  int row_min = -(h / 2), row_max = h / 2, col_min = -(w / 2), col_max = w / 2;
+  for (int d = 0; emitted < max_emitted && d <= h + w + 2; d++)
+    for (int dr = -d; dr <= d && emitted < max_emitted; dr++) {
+      int dc = d - std::abs(dr);
+      for (int step = 0; step < (dc == 0 ? 1 : 2) && emitted < max_emitted; step++) {
+        int rr = dr, cc = (step == 0 ? -dc : dc);
+        if (rr >= row_min && rr <= row_max && cc >= col_min && cc <= col_max) {
+          out.push_back({rr, cc});
+          emitted++;
+        }
+      }
+    }
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 struct Stats {
   std::vector<float> v;
@@ -539,26 +560,7 @@ void Env::init(const int32_t* blob, size_t n, const uint8_t* map, int h, int w, 
   action_success.assign(A, 0);
   rewards.assign(A, 0.f);
   episode_rewards.assign(A, 0.f);
-  // ObservationPattern (packed_coordinate.hpp:74-143): sort by (manhattan distance, dr, dc)
-  pattern.clear();
-  int hr = cfg.obs_h / 2, wr = cfg.obs_w / 2;
-  // NB: row_min = -h/2 .. row_max = h/2 (C++ int division) -- for even windows that is h+1 rows clipped by
-  // max_emitted = h*w; reproduce by walking shells exactly as the iterator does.
-  {
-    int emitted = 0, max_emitted = cfg.obs_h * cfg.obs_w;
-    int row_min = -(cfg.obs_h / 2), row_max = cfg.obs_h / 2, col_min = -(cfg.obs_w / 2), col_max = cfg.obs_w / 2;
-    for (int d = 0; emitted < max_emitted && d <= hr + wr + 2; d++)
-      for (int dr = -d; dr <= d && emitted < max_emitted; dr++) {
-        int dc = d - std::abs(dr);
-        for (int step = 0; step < (dc == 0 ? 1 : 2) && emitted < max_emitted; step++) {
-          int rr = dr, cc = (step == 0 ? -dc : dc);
-          if (rr >= row_min && rr <= row_max && cc >= col_min && cc <= col_max) {
-            pattern.push_back({rr, cc});
-            emitted++;
-          }
-        }
-      }
-  }
+  pattern = observation_pattern(cfg.obs_h, cfg.obs_w);
   // _init_buffers: initial observations with last_action = 0 (mettagrid_c.cpp:264-289); the Puffer path runs it
   // twice (ctor + set_buffers), which double-counts the tokens_* stats.
   std::vector<int32_t> zero(A, 0);
@@ -1341,6 +1343,14 @@ void mgo_set_inventory(void* h, int agent, int n, const int32_t* items, const in
     a.stats.set(e->AS.amount(item), 0.f);
   }
   for (int i = 0; i < n; i++) a.inv.update(items[i], amounts[i] - (int)a.inv.amount(items[i]));
+}
+int mgo_test_pattern(int h, int w, int32_t* out) {
+  auto p = observation_pattern(h, w);
+  for (size_t i = 0; i < p.size(); i++) {
+    out[2 * i] = p[i].first;
+    out[2 * i + 1] = p[i].second;
+  }
+  return (int)p.size();
 }
 // Known-answer hooks for the libstdc++ restatements.
 void mgo_test_shuffle(uint32_t seed, int n, int rounds, int32_t* out, uint32_t* next_raw) {

@@ -59,6 +59,8 @@ def lib() -> ct.CDLL:
     L.mgo_test_shuffle.argtypes = [ct.c_uint32, ct.c_int, ct.c_int, i32p, ct.POINTER(ct.c_uint32)]
     L.mgo_test_shared_update.argtypes = [ct.c_int, i32p, i32p, ct.c_int, i32p]
     L.mgo_test_shared_update.restype = ct.c_int
+    L.mgo_test_pattern.argtypes = [ct.c_int, ct.c_int, i32p]
+    L.mgo_test_pattern.restype = ct.c_int
     _LIB = L
     return L
 

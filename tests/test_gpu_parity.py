@@ -1,0 +1,264 @@
+"""GPU parity: the HIP step path (through the C-ABI) against the CPU oracle, the golden fixtures emitted by the
+reference, and -- when oracle/_ref travelled with the tree -- the reference's own compiled core.
+
+Bar (BASELINE.json north_star): observations, grid state, inventories bit-exact; rewards equal (they are sums of
+exactly representable f32 values here, so we require equality, which is stricter than the stated 1e-6 relative).
+"""
+
+import numpy as np
+import pytest
+
+from metta_amd.builder import make_arena, make_navigation
+from metta_amd.compile import compile_game
+from tests.fuzz_configs import fuzz_actions, rand_cfg
+from tests.helpers import digest, fixture_actions, fixture_grid, load_fixture, load_map_pool, stats_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(cfg, maps, num_envs, seeds, map_ids, passes=2):
+    from metta_amd.batch import MettaGridBatch
+
+    return MettaGridBatch(cfg, num_envs, maps, device=0, init_obs_passes=passes, seeds=seeds, map_ids=map_ids)
+
+
+def _oracles(cfg, maps, seeds, map_ids, passes=2):
+    from oracle.mg_oracle import make_oracle_env
+
+    comp = compile_game(cfg, init_obs_passes=passes)
+    return comp, [make_oracle_env(comp, comp.encode_map(maps[m]), int(s)) for s, m in zip(seeds, map_ids)]
+
+
+def _compare_step(b, oras, t, A):
+    E = len(oras)
+    obs = b.observations.cpu().numpy().reshape(E, A, -1, 3)
+    rew = b.rewards.cpu().numpy().reshape(E, A)
+    term = b.terminals.cpu().numpy().reshape(E, A)
+    trunc = b.truncations.cpu().numpy().reshape(E, A)
+    succ = b.action_success.cpu().numpy().reshape(E, A)
+    for e, o in enumerate(oras):
+        if not np.array_equal(obs[e], o.obs):
+            bad = np.argwhere(obs[e] != o.obs)
+            a = bad[0][0]
+            raise AssertionError(
+                f"step {t} env {e}: obs differ at {bad[:4].tolist()}\n hip={obs[e][a][:24].tolist()}\n ora={o.obs[a][:24].tolist()}"
+            )
+        assert np.array_equal(rew[e], o.rewards), f"step {t} env {e}: rewards {rew[e]} vs {o.rewards}"
+        assert np.array_equal(term[e], o.terminals.astype(bool)), f"step {t} env {e}: terminals"
+        assert np.array_equal(trunc[e], o.truncations.astype(bool)), f"step {t} env {e}: truncations"
+        assert np.array_equal(succ[e], o.action_success.astype(bool)), f"step {t} env {e}: action_success"
+
+
+def _compare_state(b, oras, t):
+    for e, o in enumerate(oras):
+        hs, os_ = b.agent_state(e), o.agent_state()
+        assert np.array_equal(hs, os_), f"step {t} env {e}: agent state\n{hs}\n{os_}"
+        assert np.array_equal(b.assembler_state(e), o.assembler_state()), f"step {t} env {e}: assembler state"
+        d = stats_equal(b.get_episode_stats(e), o.get_episode_stats(), ignore_invalid_variants=False)
+        assert d is None, f"step {t} env {e}: stats differ: {d}"
+        assert np.array_equal(
+            b.episode_rewards.cpu().numpy().reshape(len(oras), -1)[e], o.episode_rewards
+        ), f"step {t} env {e}: episode rewards"
+        assert b.current_step(e) == o.current_step
+
+
+def test_arena_vs_oracle():
+    cfg = make_arena(24)
+    maps = load_map_pool()[:6]
+    E, A = 12, 24
+    seeds = [0, 1, 42, 7, 1000, 2**31 + 5, 3, 4, 5, 6, 8, 9]
+    map_ids = [e % len(maps) for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, map_ids)
+    comp, oras = _oracles(cfg, maps, seeds, map_ids)
+    _compare_step(b, oras, 0, A)
+    _compare_state(b, oras, 0)
+    rs = np.random.RandomState(123)
+    for t in range(1, 401):
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        b.step(acts.reshape(-1))
+        for e, o in enumerate(oras):
+            o.step(acts[e])
+        _compare_step(b, oras, t, A)
+        if t % 100 == 0:
+            _compare_state(b, oras, t)
+    b.close()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_vs_oracle(seed):
+    rs = np.random.RandomState(seed)
+    cfg = rand_cfg(rs, device_safe=True)
+    game = cfg.game
+    passes = int(rs.randint(1, 3))
+    maps = [game.map_builder.build(np.random.default_rng(1000 * seed + i)) for i in range(3)]
+    E, A = 5, game.num_agents
+    seeds = [seed * 10 + e for e in range(E)]
+    map_ids = [e % 3 for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, map_ids, passes)
+    b.set_auto_reset(False)
+    comp, oras = _oracles(cfg, maps, seeds, map_ids, passes)
+    nA = len(comp.action_names)
+    _compare_step(b, oras, 0, A)
+    for t in range(1, 161):
+        acts = np.stack([fuzz_actions(rs, game, nA) for _ in range(E)])
+        if rs.randint(30) == 0:
+            e, ag = int(rs.randint(E)), int(rs.randint(A))
+            inv = {int(rs.randint(len(game.resource_names))): int(rs.randint(0, 400)) for _ in range(rs.randint(0, 4))}
+            b.set_inventory(e, ag, inv)
+            oras[e].set_inventory(ag, inv)
+        b.step(acts.reshape(-1))
+        for e, o in enumerate(oras):
+            o.step(acts[e])
+        _compare_step(b, oras, t, A)
+        if t % 40 == 0:
+            _compare_state(b, oras, t)
+    b.close()
+
+
+@pytest.mark.parametrize("name", ["arena24_seed1", "arena24_seed42"])
+def test_golden_arena(name):
+    """Fixture emitted by the reference (oracle/gen_golden.py): per-step digests of obs / rewards / success."""
+    z, meta = load_fixture(name)
+    cfg = make_arena(24)
+    grid = fixture_grid(z, meta)
+    b = _batch(cfg, [grid], 1, [meta["seed"]], [0])
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs0"])
+    acts = fixture_actions(meta, 24)
+    snaps = set(meta["snap_steps"])
+    for t in range(len(acts)):
+        b.step(acts[t])
+        if t % 10 == 0 or (t + 1) in snaps or t == len(acts) - 1:
+            obs = b.observations.cpu().numpy()
+            assert digest(obs) == int(z["obs_digest"][t]), f"{name}: obs digest differs at step {t + 1}"
+            assert digest(b.rewards.cpu().numpy()) == int(z["rew_digest"][t]), f"{name}: reward digest at step {t + 1}"
+            assert digest(b.action_success.cpu().numpy().astype(np.uint8)) == int(z["succ_digest"][t])
+            if (t + 1) in snaps:
+                assert np.array_equal(obs, z[f"snap_{t + 1}"])
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs_final"])
+    assert np.array_equal(b.episode_rewards.cpu().numpy(), z["episode_rewards"])
+    st = b.agent_state(0)
+    assert np.array_equal(st[:, :2], z["agent_rc"])
+    for a, inv in enumerate(meta["agent_inv"]):
+        got = [[int(st[a, 9 + 2 * k]), int(st[a, 10 + 2 * k])] for k in range(st[a, 8])]
+        assert got == inv, f"agent {a} inventory order/amounts"
+    d = stats_equal(b.get_episode_stats(0), meta["stats"])
+    assert d is None, d
+    b.close()
+
+
+def test_golden_navigation():
+    z, meta = load_fixture("navigation4_seed3")
+    cfg = make_navigation(4)
+    cfg.game.max_steps = meta["max_steps"]
+    grid = fixture_grid(z, meta)
+    b = _batch(cfg, [grid], 1, [meta["seed"]], [0])
+    b.set_auto_reset(False)
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs0"])
+    acts = fixture_actions(meta, 4)
+    for t in range(len(acts)):
+        b.step(acts[t])
+        assert digest(b.observations.cpu().numpy()) == int(z["obs_digest"][t]), f"obs digest at step {t + 1}"
+        assert digest(b.rewards.cpu().numpy()) == int(z["rew_digest"][t])
+        done = bool(b.terminals.all().item() or b.truncations.all().item())
+        assert done == (t + 1 >= meta["done_step"])
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs_final"])
+    d = stats_equal(b.get_episode_stats(0), meta["stats"])
+    assert d is None, d
+    b.close()
+
+
+def test_auto_reset_matches_puffer_semantics():
+    """`MettaGridPufferEnv.step`: when all agents are done, the NEXT step first builds a new simulation (same seed,
+    next map) and steps it (mettagrid_puffer_env.py:158-171)."""
+    from oracle.mg_oracle import make_oracle_env
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 25
+    maps = load_map_pool()[:4]
+    E, A = 3, 24
+    seeds, map_ids = [11, 12, 13], [0, 1, 2]
+    b = _batch(cfg, maps, E, seeds, map_ids)
+    b.set_auto_reset(True, 1)
+    comp, oras = _oracles(cfg, maps, seeds, map_ids)
+    cur_map = list(map_ids)
+    rs = np.random.RandomState(5)
+    episodes = 0
+    for t in range(1, 80):
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + 1) % len(maps)
+                oras[e] = make_oracle_env(comp, comp.encode_map(maps[cur_map[e]]), seeds[e])
+                episodes += 1
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+    _compare_state(b, oras, 79)
+    assert episodes == 9
+    s = b.finished_summary(clear=True)
+    assert s[0] == 9 and s[1] == 9 * 25
+    b.close()
+
+
+def test_vs_reference_core():
+    """HIP against the reference's own compiled C++ core (oracle/_ref), when it travelled with the tree."""
+    from oracle.ref_bridge import RefEnv, have_reference
+
+    if not have_reference():
+        pytest.skip("oracle/_ref not built")
+    cfg = make_arena(24)
+    maps = load_map_pool()[:2]
+    seeds, map_ids = [5, 6], [0, 1]
+    b = _batch(cfg, maps, 2, seeds, map_ids)
+    refs = [RefEnv(cfg.game, maps[m], s) for s, m in zip(seeds, map_ids)]
+    rs = np.random.RandomState(9)
+    for t in range(300):
+        acts = rs.randint(0, 5, size=(2, 24)).astype(np.int32)
+        b.step(acts.reshape(-1))
+        obs = b.observations.cpu().numpy().reshape(2, 24, 200, 3)
+        rew = b.rewards.cpu().numpy().reshape(2, 24)
+        for e, r in enumerate(refs):
+            r.step(acts[e])
+            assert np.array_equal(obs[e], r.obs), f"step {t} env {e}"
+            assert np.array_equal(rew[e], r.rewards)
+    for e, r in enumerate(refs):
+        d = stats_equal(b.get_episode_stats(e), r.env.get_episode_stats())
+        assert d is None, d
+    b.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (4096 envs x 24 agents): size-independent properties.
+    (1) determinism: two batches with the same seeds/maps/actions give identical buffers;
+    (2) replication: envs that share seed+map+actions are identical row for row;
+    (3) a sampled subset matches the oracle after K steps."""
+    import torch
+
+    cfg = make_arena(24)
+    maps = load_map_pool()
+    E, A, P = 4096, 24, len(maps)
+    seeds = [e % 512 for e in range(E)]  # env e and e+512k are replicas (512 % 64 == 0 -> same map too)
+    map_ids = [e % P for e in range(E)]
+    b1 = _batch(cfg, maps, E, seeds, map_ids)
+    b2 = _batch(cfg, maps, E, seeds, map_ids)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    K = 64
+    base_actions = torch.randint(0, 5, (K, 512, A), generator=g, dtype=torch.int32)
+    for t in range(K):
+        acts = base_actions[t].repeat(E // 512, 1).reshape(-1).cuda()
+        b1.step(acts)
+        b2.step(acts)
+    o1 = b1.observations.reshape(E // 512, 512, A, 200, 3)
+    assert torch.equal(b1.observations, b2.observations) and torch.equal(b1.rewards, b2.rewards)
+    assert torch.equal(b1.episode_rewards, b2.episode_rewards)
+    assert bool((o1 == o1[0:1]).all().item()), "replica envs diverged"
+    comp, oras = _oracles(cfg, maps, seeds[:6], map_ids[:6])
+    for t in range(K):
+        for e, o in enumerate(oras):
+            o.step(base_actions[t, e].numpy())
+    obs = b1.observations.cpu().numpy().reshape(E, A, 200, 3)
+    for e, o in enumerate(oras):
+        assert np.array_equal(obs[e], o.obs)
+        assert np.array_equal(obs[e + 512 * 3], o.obs)
+    b1.close()
+    b2.close()
