@@ -63,6 +63,11 @@ int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds,
  * is `MettaGridPufferEnv.step` (python/src/mettagrid/envs/mettagrid_puffer_env.py:158-171). */
 int mg_step(mg_handle* h, void* stream);
 
+/* As mg_step, but reads the i32[N] actions from `device_actions` (e.g. a policy's output tensor in HBM) instead
+ * of the handle's own action buffer -- the device-resident form of `np.copyto(buffers.actions, actions)` in
+ * `MettaGridPufferEnv.step` (mettagrid_puffer_env.py:166-169). */
+int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream);
+
 /* Auto-reset policy used by mg_step: enabled (0/1) and how the next map is chosen: map_id += map_stride (mod P). */
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride);
 
@@ -104,10 +109,11 @@ int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* ite
  * sum of game stat slots...}.  This is the vector the multi-GPU path all-reduces. */
 int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream);
 
-/* Timing of the most recent mg_step's kernel in milliseconds (HIP events on the stream it was launched on);
- * enable with mg_set_profiling(h, 1).  Used by bench.py for the roofline line. */
+/* Per-step kernel timing with HIP events recorded on the stream each step kernel is launched on (no host sync in
+ * the step call).  mg_set_profiling(h, 1) starts recording (up to 4096 steps); mg_profile_read waits for the
+ * recorded steps, writes their durations in milliseconds and restarts recording.  bench.py's roofline line. */
 int mg_set_profiling(mg_handle* h, int enabled);
-int mg_last_step_ms(mg_handle* h, float* ms);
+int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps);
 
 int mg_destroy(mg_handle* h);
 

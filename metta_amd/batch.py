@@ -118,12 +118,25 @@ class MettaGridBatch:
         )
 
     def step(self, actions=None) -> None:
-        """One tick of every environment; `actions` (optional) is copied into the device action buffer."""
+        """One tick of every environment.  `actions`: None (use the action buffer as is), a contiguous int32 ROCm
+        tensor (read in place, zero-copy: `mg_step_actions`), or anything else (copied into the action buffer)."""
+        torch = self._torch
         if actions is not None:
-            t = self._torch.as_tensor(actions)
+            if (
+                isinstance(actions, torch.Tensor)
+                and actions.is_cuda
+                and actions.dtype == torch.int32
+                and actions.is_contiguous()
+                and actions.device == self.device
+            ):
+                if actions.numel() != self.actions.numel():
+                    raise RuntimeError("actions has the wrong shape")
+                native.check(self.L.mg_step_actions(self._h, ct.c_void_p(actions.data_ptr()), self._stream()))
+                return
+            t = torch.as_tensor(actions)
             if t.numel() != self.actions.numel():
                 raise RuntimeError("actions has the wrong shape")
-            self.actions.copy_(t.reshape(-1).to(dtype=self._torch.int32), non_blocking=True)
+            self.actions.copy_(t.reshape(-1).to(dtype=torch.int32), non_blocking=True)
         native.check(self.L.mg_step(self._h, self._stream()))
 
     def set_auto_reset(self, enabled: bool, map_stride: int = 1) -> None:
@@ -143,10 +156,12 @@ class MettaGridBatch:
     def set_profiling(self, enabled: bool) -> None:
         native.check(self.L.mg_set_profiling(self._h, int(enabled)))
 
-    def last_step_ms(self) -> float:
-        ms = ct.c_float()
-        native.check(self.L.mg_last_step_ms(self._h, ct.byref(ms)))
-        return float(ms.value)
+    def profile_read(self, max_steps: int = 4096) -> np.ndarray:
+        """Per-step kernel durations (ms) recorded since profiling was enabled / last read."""
+        ms = np.zeros(max_steps, np.float32)
+        n = ct.c_int()
+        native.check(self.L.mg_profile_read(self._h, _p(ms, ct.c_float), max_steps, ct.byref(n)))
+        return ms[: n.value].copy()
 
     # ---- inspection ------------------------------------------------------------------------------------------
     def env_info(self, env: int) -> dict:

@@ -685,8 +685,8 @@ struct mg_handle {
   size_t lds_bytes = 0;
   bool maps_set = false;
   bool profiling = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ev_valid = false;
+  std::vector<hipEvent_t> ev;  // profiling ring: pairs (start, stop) per step
+  size_t ev_count = 0;         // steps recorded since profiling was enabled
   std::vector<std::vector<int4>> host_spawn, host_asm;  // per map (inspection)
   int* d_list = nullptr;       // scratch for reset lists [3][E]
   int* d_inv = nullptr;        // scratch for set_inventory [2][MGD_MAX_R]
@@ -785,8 +785,6 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   HIPCHK(hipMemset(k.obs, 0xFF, N * c.T * 3));
   if (dalloc(h.get(), &h->masks, N)) return 1;
   HIPCHK(hipMemset(h->masks, 1, N));
-  HIPCHK(hipEventCreate(&h->ev0));
-  HIPCHK(hipEventCreate(&h->ev1));
   *out = h.release();
   return 0;
 }
@@ -906,18 +904,31 @@ int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds,
   return 0;
 }
 
-int mg_step(mg_handle* h, void* stream) {
+#define MG_PROFILE_RING 4096
+static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
   if (!h) return fail("mg_step: NULL handle");
   if (!h->maps_set) return fail("mg_step: call mg_set_maps and mg_reset first");
   hipStream_t s = (hipStream_t)stream;
-  if (h->profiling) (void)hipEventRecord(h->ev0, s);
-  hipLaunchKernelGGL(mg_step_kernel, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_bytes, s, h->k);
-  if (h->profiling) {
-    (void)hipEventRecord(h->ev1, s);
-    h->ev_valid = true;
+  KArgs k = h->k;
+  if (actions) k.actions = actions;
+  size_t slot = 0;
+  bool prof = h->profiling && h->ev_count < MG_PROFILE_RING;
+  if (prof) {
+    slot = h->ev_count;
+    (void)hipEventRecord(h->ev[2 * slot], s);
+  }
+  hipLaunchKernelGGL(mg_step_kernel, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_bytes, s, k);
+  if (prof) {
+    (void)hipEventRecord(h->ev[2 * slot + 1], s);
+    h->ev_count++;
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+int mg_step(mg_handle* h, void* stream) { return mg_step_impl(h, nullptr, stream); }
+int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream) {
+  if (!device_actions) return fail("mg_step_actions: NULL action buffer");
+  return mg_step_impl(h, device_actions, stream);
 }
 
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride) {
@@ -1092,16 +1103,26 @@ int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream) {
 
 int mg_set_profiling(mg_handle* h, int enabled) {
   if (!h) return fail("mg_set_profiling: NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  if (enabled && h->ev.empty()) {
+    h->ev.resize(2 * MG_PROFILE_RING);
+    for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
+  }
   h->profiling = enabled != 0;
-  h->ev_valid = false;
+  h->ev_count = 0;
   return 0;
 }
 
-int mg_last_step_ms(mg_handle* h, float* ms) {
-  if (!h || !ms) return fail("mg_last_step_ms: NULL argument");
-  if (!h->ev_valid) return fail("mg_last_step_ms: profiling is off or no step was issued");
-  HIPCHK(hipEventSynchronize(h->ev1));
-  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps) {
+  if (!h || !ms || !n_steps) return fail("mg_profile_read: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  int n = (int)std::min<size_t>(h->ev_count, (size_t)std::max(max_steps, 0));
+  for (int i = 0; i < n; i++) {
+    HIPCHK(hipEventSynchronize(h->ev[2 * (size_t)i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms[i], h->ev[2 * (size_t)i], h->ev[2 * (size_t)i + 1]));
+  }
+  *n_steps = n;
+  h->ev_count = 0;
   return 0;
 }
 
@@ -1111,8 +1132,7 @@ int mg_destroy(mg_handle* h) {
   (void)hipDeviceSynchronize();
   for (void* p : h->allocs) (void)hipFree(p);
   for (void* p : h->map_allocs) (void)hipFree(p);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (auto& e : h->ev) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }

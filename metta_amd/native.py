@@ -46,6 +46,7 @@ SYMBOLS = {
     "mg_set_maps": (ct.c_int, [_vp, _u8p, ct.c_int, ct.c_int, ct.c_int]),
     "mg_reset": (ct.c_int, [_vp, _i32p, ct.c_int, _u32p, _i32p, _vp]),
     "mg_step": (ct.c_int, [_vp, _vp]),
+    "mg_step_actions": (ct.c_int, [_vp, _vp, _vp]),
     "mg_set_auto_reset": (ct.c_int, [_vp, ct.c_int, ct.c_int]),
     "mg_set_early_reset": (ct.c_int, [_vp, _u32p]),
     "mg_get_buffers": (ct.c_int, [_vp, ct.POINTER(MgBuffers)]),
@@ -59,7 +60,7 @@ SYMBOLS = {
     "mg_set_inventory": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _vp]),
     "mg_finished_summary": (ct.c_int, [_vp, _f64p, ct.c_int, _vp]),
     "mg_set_profiling": (ct.c_int, [_vp, ct.c_int]),
-    "mg_last_step_ms": (ct.c_int, [_vp, _f32p]),
+    "mg_profile_read": (ct.c_int, [_vp, _f32p, ct.c_int, ct.POINTER(ct.c_int)]),
     "mg_destroy": (ct.c_int, [_vp]),
 }
 
