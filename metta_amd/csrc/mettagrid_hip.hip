@@ -3,12 +3,12 @@
 // Replaces, for the environment-step path, the reference's pybind11 core `MettaGrid`
 // (packages/mettagrid/cpp/bindings/mettagrid_c.cpp).  Layout and kernel design: DESIGN.md.
 //
-//   mg_step_kernel   one workgroup (4 waves) per environment:
-//       stage   static map tile (shared, L2-resident pool) + agent/assembler records -> LDS
-//       phase 1 thread 0 resolves the actions in the reference's shuffled sequential order on LDS state
-//       phase 2 each wave encodes whole agents' token rows into an LDS row buffer (wave prefix-sum compaction)
-//               and streams the 0xFF-padded 600-byte rows to HBM with coalesced dword stores
-//       phase 3 rewards, termination flags, stat flush, state write-back
+//   mg_act_kernel   one wave per environment: stage the static map tile (shared, L2-resident pool) and the
+//                   agent/assembler records in LDS; resolve the actions in the reference's shuffled sequential
+//                   order; flush stat deltas; write the records back.  Restarts finished episodes first.
+//   mg_obs_kernel   one workgroup (4 waves) per environment: each wave encodes whole agents' token rows into an LDS
+//                   row buffer (wave prefix-sum compaction) and streams the 0xFF-padded 600-byte rows to HBM with
+//                   coalesced dword stores; then rewards, termination flags, token stats.
 //
 // There is no CPU fallback: every entry point runs HIP kernels or fails.
 #include <hip/hip_runtime.h>
@@ -27,9 +27,11 @@
 
 #define MG_THREADS 256
 #define MG_WIN_MARGIN 32
+#define MG_DC_LDS_MAX_WORDS 6144  // 24 KiB
 
 struct KArgs {
   const int* dc;
+  int dc_words;  // size of the device config stream; staged in LDS when it fits (MG_DC_LDS_MAX_WORDS)
   const uint16_t* map_cells;  // [P][HW]
   const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
@@ -58,6 +60,7 @@ struct KArgs {
   const int* actions;
   float* ep_rewards;
   uint8_t* success;
+  int* exec;  // [E][A] executed action of this step (last_action token)
   int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
   int auto_reset, map_stride;
   const int* reset_envs;  // reset kernel only
@@ -66,6 +69,7 @@ struct KArgs {
 };
 
 struct Lds {
+  int* dc;
   uint16_t* grid;
   DAgent* ag;
   DAsm* as;
@@ -86,13 +90,15 @@ struct Lds {
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
-                                           int ROWB, int nwaves) {
+                                           int ROWB, int nwaves, int dcw) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
     o = mg_align16(o + bytes);
     return at;
   };
+  size_t dco = take((size_t)dcw * 4);
+  if (l) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t sd = take((size_t)A * SA * 4), gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
@@ -103,6 +109,27 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
     l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
     l->flags = (int*)(base + fl); l->rows = (uint8_t*)(base + rows);
+  }
+  return o;
+}
+
+// LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
+__host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
+                                               int dcw) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4);
+  if (l) l->dc = (int*)(base + dco);
+  size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
+  if (l) {
+    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
+    l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
+    l->rows = (uint8_t*)(base + rows);
   }
   return o;
 }
@@ -276,11 +303,6 @@ __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& c
       as_[ai * a.SA + s] = (float)l.ag[ai].diversity;
       atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
     }
-    if (dm & 2u) {
-      int s = cx.AS.max_steps_without_motion();
-      as_[ai * a.SA + s] = (float)l.ag[ai].max_swm;
-      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
-    }
   }
   float* gs_ = a.gstats + (size_t)e * a.SG;
   uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
@@ -291,11 +313,76 @@ __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& c
       atomicOr(&gt_[i >> 5], 1u << (i & 31));
     }
   }
-  if (tid == 0) {
-    gs_[0] = l.tokacc[0];
-    gs_[1] = l.tokacc[1];
-    gs_[2] = l.tokacc[2];
-    atomicOr(&gt_[0], 7u);
+}
+
+// Agent::compute_stat_rewards (agent.cpp:103-132) + episode bookkeeping (bindings/mettagrid_c.cpp:656-677).
+__device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e, DEnv env, int tid, int nt) {
+  const int* dc = a.dc;
+  const MgAgentSlots AS{a.R, a.NG};
+  bool end_now = false, trunc_now = false;
+  {
+    int ms = dc[DC_MAX_STEPS];
+    if (ms > 0 && env.step >= (uint32_t)ms) {
+      end_now = true;
+      trunc_now = dc[DC_TRUNCATES] != 0;
+    }
+  }
+  bool early = env.early_reset != 0 && env.step >= env.early_reset;
+  const float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  const float* gs_ = a.gstats + (size_t)e * a.SG;
+  for (int ai = tid; ai < a.A; ai += nt) {
+    DAgent* me = &l.ag[ai];
+    const int* gr = group_rec(dc, me->group);
+    int os = gr[GR_OFF_STAT_REWARDS], ns = dc[os];
+    float reward = 0.f;
+    size_t g = (size_t)e * a.A + ai;
+    if (ns > 0) {
+      float total = 0.f;
+      for (int q = 0; q < ns; q++) {
+        const int* sr = dc + os + 1 + 5 * q;
+        int aslot = sr[0], gslot = sr[1];
+        float v = 0.f;
+        if (aslot >= 0) {
+          if (aslot >= AS.amount(0) && aslot < AS.amount(0) + a.R)
+            v = (float)me->amt[aslot - AS.amount(0)];
+          else if (aslot == AS.max_steps_without_motion())
+            v = (float)me->max_swm;
+          else if (aslot == AS.diversity())
+            v = (float)me->diversity;
+          else if (aslot < 3)
+            v = (float)me->succ[aslot];
+          else if (aslot < 6)
+            v = (float)me->fail[aslot - 3];
+          else if (aslot == AS.failed_any())
+            v = (float)(me->fail[0] + me->fail[1] + me->fail[2]);
+          else
+            v = as_[ai * a.SA + aslot];
+        }
+        if (gslot >= 0) v += gslot < 3 ? l.tokacc[gslot] : gs_[gslot];
+        float rew = v * __int_as_float(sr[2]);
+        if (sr[3]) {
+          float mx = __int_as_float(sr[4]);
+          rew = (mx < rew) ? mx : rew;
+        }
+        total += rew;
+      }
+      float delta = total - me->cur_reward;
+      if (delta != 0.0f) {
+        reward = delta;
+        me->cur_reward = total;
+        a.agents[g].cur_reward = total;
+      }
+    }
+    a.rewards[g] = reward;
+    a.ep_rewards[g] += reward;
+    if (end_now) {
+      if (trunc_now) a.trunc[g] = 1; else a.term[g] = 1;
+    }
+    if (early) a.trunc[g] = 1;
+  }
+  if (tid == 0 && (end_now || early)) {
+    a.env[e].done = 1;
+    if (early) a.env[e].early_reset = 0;
   }
 }
 
@@ -325,6 +412,22 @@ __device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t step
   const uint32_t* at_ = a.atouched + (size_t)e * nta;
   uint32_t* fat = a.fin_atouched + (size_t)e * nta;
   for (size_t i = tid; i < nta; i += nt) fat[i] = at_[i];
+  __syncthreads();
+  {  // merge the record-resident counters into the finished snapshot
+    const MgAgentSlots AS{a.R, a.NG};
+    for (int ai = tid; ai < a.A; ai += nt) {
+      const DAgent* ag = &a.agents[(size_t)e * a.A + ai];
+      float* row = fas + (size_t)ai * a.SA;
+      uint32_t fa = 0;
+      for (int h = 0; h < 3; h++) {
+        row[AS.success(h)] = (float)ag->succ[h];
+        row[AS.failed(h)] = (float)ag->fail[h];
+        fa += ag->fail[h];
+      }
+      row[AS.failed_any()] = (float)fa;
+      row[AS.max_steps_without_motion()] = (float)ag->max_swm;
+    }
+  }
   const float* gs_ = a.gstats + (size_t)e * a.SG;
   float* fgs = a.fin_gstats + (size_t)e * a.SG;
   for (int i = tid; i < a.SG; i += nt) {
@@ -368,14 +471,49 @@ __device__ inline void mg_stage_rng(const KArgs& a, const Lds& l, int e, uint32_
   }
 }
 
+// Attempted token count of one agent's observation without writing it (used for the tokens_* stats of the
+// step-0 observation when an environment restarts inside the act kernel).  One lane per agent.
+__device__ inline int mg_count_agent_tokens(const KArgs& a, const Lds& l, const int4* asm_info, int ai) {
+  const int* dc = a.dc;
+  const DAgent* me = &l.ag[ai];
+  const int oh = dc[DC_OBS_H], ow = dc[DC_OBS_W], hr = oh >> 1, wr = ow >> 1;
+  const int ar = me->r, ac = me->c;
+  int n = (dc[DC_G_COMPLETION] ? 1 : 0) + (dc[DC_G_LAST_ACTION] ? 1 : 0) + (dc[DC_G_LAST_REWARD] ? 1 : 0);
+  if (dc[DC_G_GOAL]) n += L_n(dc, group_rec(dc, me->group)[GR_OFF_GOAL]);
+  if (dc[DC_G_COMPASS]) {
+    int dr = a.H / 2 - ar, dcc = a.W / 2 - ac;
+    int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
+    if ((sr != 0 || sc != 0) && hr + sr >= 0 && hr + sr < oh && wr + sc >= 0 && wr + sc < ow) n++;
+  }
+  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN];
+  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
+  const int r_end = min(ar + hr + 1, a.H), c_end = min(ac + wr + 1, a.W);
+  for (int p = 0; p < P; p++) {
+    int packed = dc[op + p];
+    int r = ar + (packed & 0xFF) - 8, c = ac + ((packed >> 8) & 0xFF) - 8;
+    if (r < r_start || r >= r_end || c < c_start || c >= c_end) continue;
+    uint16_t cv = l.grid[r * a.W + c];
+    if (cv != 0) n += mg_object_tokens<false>(dc, l.grid, l.ag, l.as, asm_info, a.H, a.W, 0, cv, nullptr);
+  }
+  return n;
+}
+
 // ------------------------------------------------------------------------------------------------------------
-// the step kernel
+// kernel 1: actions.  One wave per environment; thread 0 resolves the actions in the reference's shuffled
+// sequential order on LDS state (bindings/mettagrid_c.cpp:572-650).
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
+#define MG_ACT_THREADS 64
+template <bool DCL>
+__global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6);
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0);
+  if (DCL) {
+    for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
+    a.dc = l.dc;
+    __syncthreads();
+  }
   DEnv env = a.env[e];
   const int* dc = a.dc;
   Ctx cx;
@@ -396,9 +534,17 @@ __global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
     mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
     mg_overlay_agents(a, l, tid, nt);
     __syncthreads();
-    mg_encode_all(a, l, e, (int)env.map_id, 0, nullptr, false, tid, nt);
+    const int4* asm_info = a.map_asm + (size_t)env.map_id * a.NAmax;
+    for (int ai = tid; ai < a.A; ai += nt) l.tok_att[ai] = mg_count_agent_tokens(a, l, asm_info, ai);
     __syncthreads();
-    if (tid == 0) mg_token_stats(a, l, dc[DC_INIT_PASSES]);
+    if (tid == 0) {
+      mg_token_stats(a, l, dc[DC_INIT_PASSES]);
+      float* gs_ = a.gstats + (size_t)e * a.SG;
+      gs_[0] = l.tokacc[0];
+      gs_[1] = l.tokacc[1];
+      gs_[2] = l.tokacc[2];
+      atomicOr(&a.gtouched[(size_t)e * a.GW], 7u);
+    }
     __syncthreads();
   } else {
     mg_load_grid(a, l, (int)env.map_id, tid, nt);
@@ -414,7 +560,6 @@ __global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
       l.dirty_amt[i] = 0;
       l.dirty_misc[i] = 0;
     }
-    if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
     __syncthreads();
     mg_overlay_agents(a, l, tid, nt);
   }
@@ -423,7 +568,6 @@ __global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
   mg_make_ctx(a, l, cx, (int)env.map_id, env.step);
   __syncthreads();
 
-  // ---- phase 1: actions, in the reference's shuffled sequential order (bindings/mettagrid_c.cpp:588-622) ----
   if (tid == 0) {
     RngWin rng{l.win, a.NWIN, 0, 0};
     mg_shuffle(l.order, a.A, rng);
@@ -471,73 +615,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
     l.flags[2] = cx.asm_dirty;
   }
   __syncthreads();
-
-  // ---- phase 2: observations (bindings/mettagrid_c.cpp:557-563) ----------------------------------------------
-  mg_encode_all(a, l, e, (int)env.map_id, env.step, l.exec, true, tid, nt);
-  __syncthreads();
-  if (tid == 0) mg_token_stats(a, l, 1);
-  __syncthreads();
-
-  // ---- phase 3: rewards, flags, stats, write-back ----------------------------------------------------------
-  bool end_now = false, trunc_now = false;
-  {
-    int ms = dc[DC_MAX_STEPS];
-    if (ms > 0 && env.step >= (uint32_t)ms) {
-      end_now = true;
-      trunc_now = dc[DC_TRUNCATES] != 0;
-    }
-  }
-  bool early = env.early_reset != 0 && env.step >= env.early_reset;
-  const float* as_ = a.astats + (size_t)e * a.A * a.SA;
-  const float* gs_ = a.gstats + (size_t)e * a.SG;
-  for (int ai = tid; ai < a.A; ai += nt) {
-    // Agent::compute_stat_rewards (agent.cpp:103-132)
-    DAgent* me = &l.ag[ai];
-    const int* gr = group_rec(dc, me->group);
-    int os = gr[GR_OFF_STAT_REWARDS], ns = dc[os];
-    float reward = 0.f;
-    if (ns > 0) {
-      float total = 0.f;
-      for (int q = 0; q < ns; q++) {
-        const int* sr = dc + os + 1 + 5 * q;
-        int aslot = sr[0], gslot = sr[1];
-        float v = 0.f;
-        if (aslot >= 0) {
-          if (aslot >= cx.AS.amount(0) && aslot < cx.AS.amount(0) + a.R)
-            v = (float)me->amt[aslot - cx.AS.amount(0)];
-          else if (aslot == cx.AS.max_steps_without_motion())
-            v = (float)me->max_swm;
-          else if (aslot == cx.AS.diversity())
-            v = (float)me->diversity;
-          else
-            v = as_[ai * a.SA + aslot] + (float)l.sd[ai * a.SA + aslot];
-        }
-        if (gslot >= 0) {
-          float gv = gslot < 3 ? l.tokacc[gslot] : gs_[gslot] + (float)l.gd[gslot];
-          v += gv;
-        }
-        float rew = v * __int_as_float(sr[2]);
-        if (sr[3]) {
-          float mx = __int_as_float(sr[4]);
-          rew = (mx < rew) ? mx : rew;
-        }
-        total += rew;
-      }
-      float delta = total - me->cur_reward;
-      if (delta != 0.0f) {
-        reward = delta;
-        me->cur_reward = total;
-      }
-    }
-    size_t g = (size_t)e * a.A + ai;
-    a.rewards[g] = reward;
-    a.ep_rewards[g] += reward;
-    if (end_now) {
-      if (trunc_now) a.trunc[g] = 1; else a.term[g] = 1;
-    }
-    if (early) a.trunc[g] = 1;
-  }
-  __syncthreads();
+  for (int i = tid; i < a.A; i += nt) a.exec[(size_t)e * a.A + i] = l.exec[i];
   mg_flush_stats(a, l, cx, e, tid, nt);
   {
     uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
@@ -556,12 +634,52 @@ __global__ __launch_bounds__(MG_THREADS) void mg_step_kernel(KArgs a) {
     }
     if (tid == 0) {
       env.mt_idx = new_idx;
-      if (end_now || early) env.done = 1;
-      if (early) env.early_reset = 0;
       if (l.flags[1]) env.error |= 1u;
       a.env[e] = env;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// kernel 2: observations + rewards + episode flags.  One workgroup (4 waves) per environment; each wave encodes
+// whole agents' token rows in LDS and streams them to HBM (bindings/mettagrid_c.cpp:652-677).
+// ------------------------------------------------------------------------------------------------------------
+template <bool DCL>
+__global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
+  Lds l;
+  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0);
+  if (DCL) {
+    for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
+    a.dc = l.dc;
+  }
+  DEnv env = a.env[e];
+  mg_load_grid(a, l, (int)env.map_id, tid, nt);
+  {
+    const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
+    uint4* dst = (uint4*)l.ag;
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
+    uint4* d2 = (uint4*)l.as;
+    for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+    for (int i = tid; i < a.A; i += nt) l.exec[i] = a.exec[(size_t)e * a.A + i];
+    if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+  }
+  __syncthreads();
+  mg_overlay_agents(a, l, tid, nt);
+  __syncthreads();
+  mg_encode_all(a, l, e, (int)env.map_id, env.step, l.exec, true, tid, nt);
+  __syncthreads();
+  if (tid == 0) {
+    mg_token_stats(a, l, 1);
+    float* gs_ = a.gstats + (size_t)e * a.SG;
+    gs_[0] = l.tokacc[0];
+    gs_[1] = l.tokacc[1];
+    gs_[2] = l.tokacc[2];
+  }
+  __syncthreads();
+  mg_rewards_and_flags(a, l, e, env, tid, nt);
 }
 
 // Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.
@@ -570,7 +688,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6);
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0);
   DEnv env = a.env[e];
   env.seed = a.reset_seeds[blockIdx.x];
   env.map_id = (uint32_t)a.reset_maps[blockIdx.x];
@@ -586,7 +704,14 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   __syncthreads();
   mg_encode_all(a, l, e, (int)env.map_id, 0, nullptr, true, tid, nt);
   __syncthreads();
-  if (tid == 0) mg_token_stats(a, l, a.dc[DC_INIT_PASSES]);
+  if (tid == 0) {
+    mg_token_stats(a, l, a.dc[DC_INIT_PASSES]);
+    float* gs_ = a.gstats + (size_t)e * a.SG;
+    gs_[0] = l.tokacc[0];
+    gs_[1] = l.tokacc[1];
+    gs_[2] = l.tokacc[2];
+    atomicOr(&a.gtouched[(size_t)e * a.GW], 7u);
+  }
   __syncthreads();
   mg_flush_stats(a, l, cx, e, tid, nt);
   uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
@@ -682,7 +807,8 @@ struct mg_handle {
   KArgs k;
   std::vector<void*> allocs;
   std::vector<void*> map_allocs;
-  size_t lds_bytes = 0;
+  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0;
+  bool dc_lds = false;
   bool maps_set = false;
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // profiling ring: pairs (start, stop) per step
@@ -754,6 +880,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &d_dc, dcfg.size())) return 1;
   HIPCHK(hipMemcpy(d_dc, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice));
   k.dc = d_dc;
+  k.dc_words = (int)dcfg.size();
   size_t N = (size_t)num_envs * c.A;
   if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
@@ -780,6 +907,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   }
   if (dalloc(h.get(), &k.ep_rewards, N)) return 1;
   if (dalloc(h.get(), &k.success, N)) return 1;
+  if (dalloc(h.get(), &k.exec, N)) return 1;
   if (dalloc(h.get(), &h->d_list, (size_t)num_envs * 3)) return 1;
   if (dalloc(h.get(), &h->d_inv, (size_t)2 * MGD_MAX_R)) return 1;
   HIPCHK(hipMemset(k.obs, 0xFF, N * c.T * 3));
@@ -850,7 +978,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   }
   h->host_asm = asm_lists;
   // LDS budget
-  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64);
+  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0);
   if (lds > 160 * 1024)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   for (void* p : h->map_allocs) (void)hipFree(p);
@@ -871,7 +999,22 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   k.asms = d_asms;
   k.P = num_maps; k.H = height; k.W = width; k.HW = HWp; k.NAmax = NAmax;
   h->lds_bytes = lds;
-  HIPCHK(hipFuncSetAttribute((const void*)mg_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
+  int dcw = h->dc_lds ? k.dc_words : 0;
+  h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw);
+  if (h->lds_act > 160 * 1024 || h->lds_obs > 160 * 1024) {
+    h->dc_lds = false;
+    h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0);
+    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0);
+  }
+  if (h->dc_lds) {
+    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+  }
   HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   h->maps_set = true;
   return 0;
@@ -917,7 +1060,13 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
     slot = h->ev_count;
     (void)hipEventRecord(h->ev[2 * slot], s);
   }
-  hipLaunchKernelGGL(mg_step_kernel, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_bytes, s, k);
+  if (h->dc_lds) {
+    hipLaunchKernelGGL(mg_act_kernel<true>, dim3((unsigned)h->E), dim3(MG_ACT_THREADS), h->lds_act, s, k);
+    hipLaunchKernelGGL(mg_obs_kernel<true>, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_obs, s, k);
+  } else {
+    hipLaunchKernelGGL(mg_act_kernel<false>, dim3((unsigned)h->E), dim3(MG_ACT_THREADS), h->lds_act, s, k);
+    hipLaunchKernelGGL(mg_obs_kernel<false>, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_obs, s, k);
+  }
   if (prof) {
     (void)hipEventRecord(h->ev[2 * slot + 1], s);
     h->ev_count++;
@@ -996,8 +1145,28 @@ int mg_episode_stats(mg_handle* h, int env, int last_finished, float* agent_valu
   HIPCHK(hipMemcpy(at.data(), (last_finished ? k.fin_atouched : k.atouched) + (size_t)env * nta, nta * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(game_values, (last_finished ? k.fin_gstats : k.gstats) + (size_t)env * k.SG, (size_t)k.SG * 4, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(gt.data(), (last_finished ? k.fin_gtouched : k.gtouched) + (size_t)env * k.GW, (size_t)k.GW * 4, hipMemcpyDeviceToHost));
+  if (!last_finished) {  // merge the record-resident counters (see DAgent)
+    std::vector<DAgent> ag((size_t)k.A);
+    HIPCHK(hipMemcpy(ag.data(), k.agents + (size_t)env * k.A, ag.size() * sizeof(DAgent), hipMemcpyDeviceToHost));
+    const MgAgentSlots AS = h->cfg.aslots();
+    for (int a = 0; a < k.A; a++) {
+      float* row = agent_values + (size_t)a * k.SA;
+      uint32_t fa = 0;
+      for (int q = 0; q < 3; q++) {
+        row[AS.success(q)] = (float)ag[(size_t)a].succ[q];
+        row[AS.failed(q)] = (float)ag[(size_t)a].fail[q];
+        fa += ag[(size_t)a].fail[q];
+      }
+      row[AS.failed_any()] = (float)fa;
+      row[AS.max_steps_without_motion()] = (float)ag[(size_t)a].max_swm;
+    }
+  }
+  // a key exists once touched: explicit bit (set-type slots) or a non-zero value (counters only grow from 0)
   for (int a = 0; a < k.A; a++)
-    for (int s = 0; s < k.SA; s++) agent_touched[(size_t)a * k.SA + s] = (at[(size_t)a * k.TW + (s >> 5)] >> (s & 31)) & 1u;
+    for (int s = 0; s < k.SA; s++) {
+      uint32_t bit = (at[(size_t)a * k.TW + (s >> 5)] >> (s & 31)) & 1u;
+      agent_touched[(size_t)a * k.SA + s] = (bit || agent_values[(size_t)a * k.SA + s] != 0.f) ? 1 : 0;
+    }
   for (int s = 0; s < k.SG; s++) game_touched[s] = (gt[(size_t)(s >> 5)] >> (s & 31)) & 1u;
   return 0;
 }

@@ -17,7 +17,7 @@
 #define MG_IDX_MASK 0x1FFF
 #define MG_CELL(kind, idx) ((uint16_t)(((kind) << MG_KIND_SHIFT) | (idx)))
 
-struct __align__(16) DAgent {  // 80 bytes; one per agent, [E][A] in HBM, staged in LDS during a step
+struct __align__(16) DAgent {  // 112 bytes; one per agent, [E][A] in HBM, staged in LDS during a step
   uint16_t r, c, prev_r, prev_c;
   int16_t frozen;
   uint8_t vibe, group;
@@ -28,8 +28,13 @@ struct __align__(16) DAgent {  // 80 bytes; one per agent, [E][A] in HBM, staged
   uint8_t order[MGD_MAX_R];  // unordered_map iteration order of the inventory
   uint8_t n_items, nb, next_resize, diversity;
   uint16_t presence, pad;
+  // Hot per-step counters live in the record (it is streamed every step anyway) instead of the stat array:
+  // action.<noop|move|change_vibe>.success / .failed; action.failed is their sum; max_swm above.
+  // mg_episode_stats merges them back into the reference's key set.
+  uint32_t succ[3], fail[3];
+  uint32_t pad2[2];
 };
-static_assert(sizeof(DAgent) == 80, "DAgent layout");
+static_assert(sizeof(DAgent) == 112, "DAgent layout");
 
 struct __align__(16) DAsm {  // assembler.hpp:245-259
   uint32_t cooldown_end, cooldown_duration, uses_count, clipped;
@@ -657,23 +662,19 @@ __device__ inline bool mg_handle_action(Ctx& cx, int ai, int kind, int arg) {
   }
   if (actor->r == actor->prev_r && actor->c == actor->prev_c) {
     actor->swm += 1;
-    if ((float)actor->swm > (float)actor->max_swm) {  // both exact in f32 below 2^24; compared as floats upstream
-      actor->max_swm = actor->swm;
-      cx.dirty_misc[ai] |= 2u;
-    }
+    if (actor->swm > actor->max_swm) actor->max_swm = actor->swm;  // stat status.max_steps_without_motion
   } else {
     actor->swm = 0;
   }
   actor->prev_r = actor->r;
   actor->prev_c = actor->c;
   if (success) {
-    sda[cx.AS.success(kind)] += 1;
+    actor->succ[kind] += 1;
     int oc = dc[DC_OFF_HANDLERS + 2 * kind + 1], nc = L_n(dc, oc);
     for (int i = 0; i < nc; i++)
       if (KV_v(dc, oc, i) > 0) inv_update(cx, ai, KV_k(dc, oc, i), -(KV_v(dc, oc, i) & 0xFFFF));
   } else {
-    sda[cx.AS.failed(kind)] += 1;
-    sda[cx.AS.failed_any()] += 1;
+    actor->fail[kind] += 1;  // action.failed == sum of the per-handler failures
   }
   return success;
 }
