@@ -38,6 +38,7 @@ struct KArgs {
   const int* map_nasm;        // [P]
   const float* map_objcount;  // [P][n_cells]
   int P, H, W, HW, NAmax, n_cells;
+  int NW, TS, NOBJ;  // wall types, token-list stride (tokens per object), objects per env (NW + A + NAmax)
   DEnv* env;
   uint32_t* mt;  // [E][624]
   DAgent* agents;
@@ -85,12 +86,15 @@ struct Lds {
   float* tokacc;  // [3] tokens_written / dropped / free_space accumulators
   int* flags;     // [4]
   uint8_t* rows;
+  uint8_t* ocnt;    // [NOBJ] tokens of each object this step
+  uint16_t* heap;   // [NOBJ][TS] (feature | value << 8)
+  uint32_t* pat;    // [P] (dr+8) | (dc+8) << 8 | location byte << 16
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
-                                           int ROWB, int nwaves, int dcw) {
+                                           int ROWB, int nwaves, int dcw, int NOBJ, int TS, int NP) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -103,7 +107,9 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   size_t sd = take((size_t)A * SA * 4), gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
+  size_t oc = take(nwaves ? (size_t)NOBJ : 0), hp = take(nwaves ? (size_t)NOBJ * TS * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
   if (l) {
+    l->ocnt = (uint8_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->sd = (int*)(base + sd);
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
@@ -115,7 +121,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
 
 // LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
 __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
-                                               int dcw) {
+                                               int dcw, int NOBJ, int TS, int NP) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -126,7 +132,9 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   if (l) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
+  size_t oc = take((size_t)NOBJ), hp = take((size_t)NOBJ * TS * 2), pt = take((size_t)NP * 4);
   if (l) {
+    l->ocnt = (uint8_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
     l->rows = (uint8_t*)(base + rows);
@@ -150,21 +158,129 @@ __device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, in
 }
 
 __device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
-  for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = MG_CELL(MG_CELL_AGENT, i);
+  const CellCodec cc{a.NW, a.A};
+  for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = cc.agent(i);
+}
+
+// Build every object's token list once (they are observer independent) and the pattern table.
+__device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
+  const int* dc = a.dc;
+  const CellCodec cc{a.NW, a.A};
+  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  const int nasm = a.map_nasm[map_id];
+  for (int obj = tid; obj < a.NOBJ; obj += nt) {
+    PairOut out{l.heap + (size_t)obj * a.TS, 0};
+    if (obj < a.NW + a.A + nasm)
+      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out);
+    l.ocnt[obj] = (uint8_t)out.n;
+  }
+  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
+  for (int p = tid; p < P; p += nt) {
+    uint32_t packed = (uint32_t)dc[op + p];
+    int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
+    l.pat[p] = packed | ((uint32_t)(((dr + hr) << 4) | ((dcc + wr) & 0x0F)) << 16);
+  }
+}
+
+// One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
+// MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
+__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t step, int ai, int action, uint8_t* row,
+                                      int lane) {
+  const int* dc = a.dc;
+  const DAgent* me = &l.ag[ai];
+  const int T = a.T, oh = dc[DC_OBS_H], ow = dc[DC_OBS_W], hr = oh >> 1, wr = ow >> 1;
+  const int ar = me->r, ac = me->c, H = a.H, W = a.W;
+  int base = 0;
+  if (lane == 0) {  // global tokens + compass at/around the centre (a handful; one lane)
+    uint8_t loc = (uint8_t)((hr << 4) | (wr & 0x0F));
+    auto put = [&](uint8_t lc, int f, int v) {
+      if (base < T) {
+        row[base * 3 + 0] = lc;
+        row[base * 3 + 1] = (uint8_t)f;
+        row[base * 3 + 2] = (uint8_t)v;
+      }
+      base++;
+    };
+    if (dc[DC_G_COMPLETION]) {
+      int pct = 0, ms = dc[DC_MAX_STEPS];
+      if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
+      put(loc, dc[DC_FID0 + MG_F_COMPLETION], pct);
+    }
+    if (dc[DC_G_LAST_ACTION]) put(loc, dc[DC_FID0 + MG_F_LAST_ACTION], action);
+    // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
+    if (dc[DC_G_LAST_REWARD]) put(loc, dc[DC_FID0 + MG_F_LAST_REWARD], 0);
+    if (dc[DC_G_GOAL]) {
+      int og = group_rec(dc, me->group)[GR_OFF_GOAL], ng = L_n(dc, og);
+      for (int i = 0; i < ng; i++) put(loc, dc[DC_FID0 + MG_F_GOAL], L_at(dc, og, i));
+    }
+    if (dc[DC_G_COMPASS]) {
+      int dr = H / 2 - ar, dcc = W / 2 - ac;
+      int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
+      int orr = hr + sr, occ = wr + sc;
+      if ((sr != 0 || sc != 0) && orr >= 0 && orr < oh && occ >= 0 && occ < ow)
+        put((uint8_t)((orr << 4) | (occ & 0x0F)), dc[DC_FID0 + MG_F_COMPASS], 1);
+    }
+  }
+  base = __shfl(base, 0, 64);
+  const int P = dc[DC_PATTERN_N];
+  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
+  const int r_end = min(ar + hr + 1, H), c_end = min(ac + wr + 1, W);
+  for (int p0 = 0; p0 < P; p0 += 64) {
+    int p = p0 + lane;
+    int cnt = 0, obj = 0;
+    uint32_t pk = 0;
+    if (p < P) {
+      pk = l.pat[p];
+      int r = ar + (int)(pk & 0xFF) - 8, c = ac + (int)((pk >> 8) & 0xFF) - 8;
+      if (r >= r_start && r < r_end && c >= c_start && c < c_end) {
+        uint16_t cv = l.grid[r * W + c];
+        if (cv != 0) {
+          obj = (int)cv - 1;
+          cnt = l.ocnt[obj];
+        }
+      }
+    }
+    // exclusive prefix sum of cnt over the wave: ones via mbcnt, the few multi-token objects by a uniform loop
+    unsigned long long any = __ballot(cnt > 0);
+    unsigned long long big = __ballot(cnt > 1);
+    int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0));
+    int total = __popcll(any);
+    while (big) {
+      int j = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      int cj = __builtin_amdgcn_readlane(cnt, j) - 1;
+      total += cj;
+      if (lane > j) off += cj;
+    }
+    off += base;
+    if (cnt > 0 && off < T) {
+      const uint16_t* src = l.heap + (size_t)obj * a.TS;
+      uint8_t loc = (uint8_t)(pk >> 16);
+      int n = min(cnt, T - off);
+      uint8_t* dst = row + off * 3;
+      for (int k = 0; k < n; k++) {
+        uint16_t fv = src[k];
+        dst[k * 3 + 0] = loc;
+        dst[k * 3 + 1] = (uint8_t)(fv & 0xFF);
+        dst[k * 3 + 2] = (uint8_t)(fv >> 8);
+      }
+    }
+    base += total;
+  }
+  return base;
 }
 
 // All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
-__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, int map_id, uint32_t step, const int* exec,
+// Requires mg_build_tokens + a barrier before.
+__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                      bool write_global, int tid, int nt) {
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
   uint8_t* row = l.rows + (size_t)wave * a.ROWB;
   const int row_bytes = a.T * 3;
-  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
   for (int ai = wave; ai < a.A; ai += nwaves) {
     for (int i = lane; i < (a.ROWB >> 2); i += 64) ((uint32_t*)row)[i] = 0xFFFFFFFFu;
     __builtin_amdgcn_wave_barrier();
-    int attempted =
-        mg_encode_agent(a.dc, l.grid, l.ag, l.as, asm_info, a.H, a.W, step, ai, exec ? exec[ai] : 0, row, lane);
+    int attempted = mg_encode_agent(a, l, step, ai, exec ? exec[ai] : 0, row, lane);
     if (lane == 0) l.tok_att[ai] = attempted;
     __builtin_amdgcn_wave_barrier();
     if (write_global) {
@@ -401,6 +517,7 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int ma
   cx.asm_dirty = 0;
   cx.AS = MgAgentSlots{a.R, a.NG};
   cx.GS = MgGameSlots{a.R, a.n_cells - 1};
+  cx.cc = CellCodec{a.NW, a.A};
 }
 
 // Keep the finished episode's stats for the host and add it to the device-wide summary.
@@ -493,7 +610,11 @@ __device__ inline int mg_count_agent_tokens(const KArgs& a, const Lds& l, const 
     int r = ar + (packed & 0xFF) - 8, c = ac + ((packed >> 8) & 0xFF) - 8;
     if (r < r_start || r >= r_end || c < c_start || c >= c_end) continue;
     uint16_t cv = l.grid[r * a.W + c];
-    if (cv != 0) n += mg_object_tokens<false>(dc, l.grid, l.ag, l.as, asm_info, a.H, a.W, 0, cv, nullptr);
+    if (cv != 0) {
+      CountOut co{0};
+      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, CellCodec{a.NW, a.A}, a.H, a.W, 0, cv, co);
+      n += co.n;
+    }
   }
   return n;
 }
@@ -508,7 +629,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0);
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
   if (DCL) {
     for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
     a.dc = l.dc;
@@ -649,7 +770,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
   Lds l;
-  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0);
+  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0, a.NOBJ, a.TS, a.dc[DC_PATTERN_N]);
   if (DCL) {
     for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
     a.dc = l.dc;
@@ -669,7 +790,9 @@ __global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
   __syncthreads();
   mg_overlay_agents(a, l, tid, nt);
   __syncthreads();
-  mg_encode_all(a, l, e, (int)env.map_id, env.step, l.exec, true, tid, nt);
+  mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);
+  __syncthreads();
+  mg_encode_all(a, l, e, env.step, l.exec, true, tid, nt);
   __syncthreads();
   if (tid == 0) {
     mg_token_stats(a, l, 1);
@@ -688,7 +811,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0);
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.TS, a.dc[DC_PATTERN_N]);
   DEnv env = a.env[e];
   env.seed = a.reset_seeds[blockIdx.x];
   env.map_id = (uint32_t)a.reset_maps[blockIdx.x];
@@ -702,7 +825,9 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
   mg_overlay_agents(a, l, tid, nt);
   __syncthreads();
-  mg_encode_all(a, l, e, (int)env.map_id, 0, nullptr, true, tid, nt);
+  mg_build_tokens(a, l, (int)env.map_id, 0, tid, nt);
+  __syncthreads();
+  mg_encode_all(a, l, e, 0, nullptr, true, tid, nt);
   __syncthreads();
   if (tid == 0) {
     mg_token_stats(a, l, a.dc[DC_INIT_PASSES]);
@@ -747,7 +872,7 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   cx.dc = a.dc; cx.grid = nullptr; cx.ag = ag; cx.as = nullptr; cx.asm_info = nullptr; cx.sd = sd; cx.gd = nullptr;
   cx.dirty_amt = &dirty[0]; cx.dirty_misc = &dirty[1];
   cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
-  cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1};
+  cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A};
   float* as_ = a.astats + ((size_t)e * a.A + agent) * a.SA;
   uint32_t* at_ = a.atouched + ((size_t)e * a.A + agent) * a.TW;
   uint8_t existing[MGD_MAX_R];
@@ -854,7 +979,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   for (const auto& g : c.groups)
     if (!g.damage_threshold.empty() && !g.damage_resources.empty())
       return fail("mg_create: agent damage is not supported on the device path yet");
-  if (c.A > MG_IDX_MASK) return fail("mg_create: too many agents per environment");
+  if (c.A > 8191) return fail("mg_create: too many agents per environment");
   for (const auto& a : c.assemblers) {
     if (a.chest_search_distance > 0 && !c.chests.empty()) return fail("mg_create: chest search unsupported");
     for (const auto& p : a.protocols)
@@ -926,6 +1051,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   KArgs& k = h->k;
   const int HW = height * width;
   const int HWp = (HW + 1) & ~1;  // keep each map 4-byte aligned
+  const CellCodec codec{(int)c.walls.size(), c.A};
   std::vector<uint16_t> cells((size_t)num_maps * HWp, 0);
   std::vector<int4> spawn((size_t)num_maps * c.A);
   std::vector<std::vector<int4>> asm_lists((size_t)num_maps);
@@ -946,7 +1072,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
         uint16_t* dst = &cells[(size_t)m * HWp + (size_t)r * width + cc];
         switch (cell.kind) {
           case MG_CELL_WALL:
-            *dst = MG_CELL(MG_CELL_WALL, cell.idx);
+            *dst = codec.wall(cell.idx);
             objcount[(size_t)m * c.cells.size() + code] += 1.f;
             break;
           case MG_CELL_AGENT:
@@ -954,8 +1080,9 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
             n_agents++;
             break;
           case MG_CELL_ASSEMBLER:
-            if (asm_lists[(size_t)m].size() >= (size_t)MG_IDX_MASK) return fail("mg_set_maps: too many assemblers");
-            *dst = MG_CELL(MG_CELL_ASSEMBLER, (int)asm_lists[(size_t)m].size());
+            if ((size_t)c.walls.size() + c.A + asm_lists[(size_t)m].size() + 1 >= (size_t)MG_MAX_OBJECTS)
+              return fail("mg_set_maps: too many objects for uint16 cells");
+            *dst = codec.assembler((int)asm_lists[(size_t)m].size());
             asm_lists[(size_t)m].push_back(make_int4(r, cc, cell.idx, (int)id));
             objcount[(size_t)m * c.cells.size() + code] += 1.f;
             break;
@@ -978,7 +1105,20 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   }
   h->host_asm = asm_lists;
   // LDS budget
-  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0);
+  // token-list stride: the most tokens any object can show (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578)
+  int TS = 1;
+  for (const auto& wl : c.walls) TS = std::max(TS, (int)wl.tags.size() + 1);
+  for (const auto& g : c.groups) TS = std::max(TS, 3 + c.R * c.n_inv_tokens + (int)g.tags.size());
+  for (const auto& a : c.assemblers) {
+    int io = 0;
+    for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
+    TS = std::max(TS, 3 + io + (int)a.tags.size() + 1);
+  }
+  if (TS > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
+  const int NOBJ = (int)c.walls.size() + c.A + NAmax;
+  const int NP = c.obs_h * c.obs_w;
+  k.NW = (int)c.walls.size(); k.TS = TS; k.NOBJ = NOBJ;
+  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, TS, NP);
   if (lds > 160 * 1024)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   for (void* p : h->map_allocs) (void)hipFree(p);
@@ -1001,12 +1141,12 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   h->lds_bytes = lds;
   h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
-  h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw);
+  h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw, NOBJ, TS, NP);
   if (h->lds_act > 160 * 1024 || h->lds_obs > 160 * 1024) {
     h->dc_lds = false;
-    h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0);
-    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0);
+    h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
+    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, TS, NP);
   }
   if (h->dc_lds) {
     HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));

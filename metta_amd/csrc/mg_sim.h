@@ -13,9 +13,25 @@
 
 #include "mg_device_cfg.h"
 
-#define MG_KIND_SHIFT 13
-#define MG_IDX_MASK 0x1FFF
-#define MG_CELL(kind, idx) ((uint16_t)(((kind) << MG_KIND_SHIFT) | (idx)))
+// Grid cell encoding (uint16): 0 = empty, else 1 + object index in the env's unified object numbering
+//   [0, NW) wall types | [NW, NW + A) agents | [NW + A, NW + A + NA) assembler instances of the map.
+// Walls carry no per-instance state, so a wall cell names its *type*; the static layer of a map (walls,
+// assemblers) is shared by every environment that plays it, agents are overlaid per environment.
+#define MG_MAX_OBJECTS 65534
+struct CellCodec {
+  int NW, A;
+  __host__ __device__ __forceinline__ int kind(uint16_t v) const {
+    int o = (int)v - 1;
+    return v == 0 ? MG_CELL_EMPTY : (o < NW ? MG_CELL_WALL : (o < NW + A ? MG_CELL_AGENT : MG_CELL_ASSEMBLER));
+  }
+  __host__ __device__ __forceinline__ bool is_agent(uint16_t v) const { return (int)v > NW && (int)v <= NW + A; }
+  __host__ __device__ __forceinline__ int agent_idx(uint16_t v) const { return (int)v - 1 - NW; }
+  __host__ __device__ __forceinline__ int asm_idx(uint16_t v) const { return (int)v - 1 - NW - A; }
+  __host__ __device__ __forceinline__ int wall_idx(uint16_t v) const { return (int)v - 1; }
+  __host__ __device__ __forceinline__ uint16_t agent(int i) const { return (uint16_t)(1 + NW + i); }
+  __host__ __device__ __forceinline__ uint16_t assembler(int i) const { return (uint16_t)(1 + NW + A + i); }
+  __host__ __device__ __forceinline__ uint16_t wall(int t) const { return (uint16_t)(1 + t); }
+};
 
 struct __align__(16) DAgent {  // 112 bytes; one per agent, [E][A] in HBM, staged in LDS during a step
   uint16_t r, c, prev_r, prev_c;
@@ -60,6 +76,7 @@ struct Ctx {
   int asm_dirty;
   MgAgentSlots AS;
   MgGameSlots GS;
+  CellCodec cc;
 };
 
 // ---- small list helpers over the dcfg stream ----------------------------------------------------------------
@@ -278,8 +295,8 @@ __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item
 
 // ---- assembler ---------------------------------------------------------------------------------------------
 // Assembler::get_current_protocol (assembler.hpp:353-408).  Returns the protocol record offset or -1.
-__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, int H, int W, int ar,
-                                          int ac, int cfg, bool clipped) {
+__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, CellCodec codec, int H,
+                                          int W, int ar, int ac, int cfg, bool clipped) {
   uint8_t vibes[8];
   int nv = 0, n_agents = 0;
   for (int i = -1; i <= 1; i++)
@@ -288,9 +305,9 @@ __device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, c
       int rr = ar + i, cc = ac + j;
       if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
       uint16_t cv = grid[rr * W + cc];
-      if ((cv >> MG_KIND_SHIFT) == MG_CELL_AGENT) {
+      if (codec.is_agent(cv)) {
         n_agents++;
-        uint8_t v = ag[cv & MG_IDX_MASK].vibe;
+        uint8_t v = ag[codec.agent_idx(cv)].vibe;
         if (v != 0) {  // insertion sort (std::sort of the vibe vector)
           int p = nv++;
           while (p > 0 && vibes[p - 1] > v) {
@@ -340,7 +357,7 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
   uint32_t remaining = as->cooldown_end <= cx.step ? 0 : as->cooldown_end - cx.step;
   bool partial = rec[AR_ALLOW_PARTIAL] != 0;
   if (remaining > 0 && !partial) return false;
-  int po = mg_current_protocol(dc, cx.grid, cx.ag, cx.H, cx.W, ar, ac, info.z, as->clipped != 0);
+  int po = mg_current_protocol(dc, cx.grid, cx.ag, cx.cc, cx.H, cx.W, ar, ac, info.z, as->clipped != 0);
   if (po < 0) return false;
   // protocol_to_use as (item, amount) lists
   int in_k[MGD_MAX_R], in_v[MGD_MAX_R], out_k[MGD_MAX_R], out_v[MGD_MAX_R];
@@ -400,7 +417,7 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
   for (int q = 0; q < np; q++) {
     int p = (start + q) % np;
     uint16_t cv = cx.grid[pr[p] * cx.W + pc[p]];
-    if ((cv >> MG_KIND_SHIFT) == MG_CELL_AGENT) near[nn++] = cv & MG_IDX_MASK;
+    if (cx.cc.is_agent(cv)) near[nn++] = cx.cc.agent_idx(cv);
   }
   // can_afford_protocol: uint16 totals (assembler.hpp:124-137)
   for (int i = 0; i < n_in; i++) {
@@ -467,8 +484,8 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
 // ---- attack / transfer (attack.hpp:93-253, transfer.hpp:72-150) ----------------------------------------------
 __device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
   const int* dc = cx.dc;
-  if ((target_cell >> MG_KIND_SHIFT) != MG_CELL_AGENT) return false;
-  int ti = target_cell & MG_IDX_MASK;
+  if (!cx.cc.is_agent(target_cell)) return false;
+  int ti = cx.cc.agent_idx(target_cell);
   DAgent* actor = &cx.ag[ai];
   DAgent* target = &cx.ag[ti];
   if (target->frozen > 0) return false;
@@ -541,8 +558,8 @@ __device__ inline bool mg_try_transfer(Ctx& cx, int ai, uint16_t target_cell) {
   int orq = dc[DC_OFF_XFER_REQUIRED], nrq = L_n(dc, orq);
   for (int i = 0; i < nrq; i++)
     if ((int)actor->amt[KV_k(dc, orq, i)] < (KV_v(dc, orq, i) & 0xFFFF)) return false;
-  if ((target_cell >> MG_KIND_SHIFT) != MG_CELL_AGENT) return false;
-  int ti = target_cell & MG_IDX_MASK;
+  if (!cx.cc.is_agent(target_cell)) return false;
+  int ti = cx.cc.agent_idx(target_cell);
   DAgent* target = &cx.ag[ti];
   if (target->frozen > 0) return false;
   int oe = dc[DC_OFF_XFER_EFFECTS], ne = dc[oe];
@@ -604,20 +621,20 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
   } else if (vh == MG_VH_TRANSFER) {
     if (mg_try_transfer(cx, ai, target)) return true;
   }
-  int kind = target >> MG_KIND_SHIFT;
+  int kind = cx.cc.kind(target);
   if (kind == MG_CELL_EMPTY) {
-    cx.grid[tr * cx.W + tc] = MG_CELL(MG_CELL_AGENT, ai);
+    cx.grid[tr * cx.W + tc] = cx.cc.agent(ai);
     cx.grid[(int)actor->r * cx.W + actor->c] = 0;
     actor->r = (uint16_t)tr;
     actor->c = (uint16_t)tc;
     return true;
   }
   if (kind == MG_CELL_AGENT) {
-    int ti = target & MG_IDX_MASK;
+    int ti = cx.cc.agent_idx(target);
     DAgent* ta = &cx.ag[ti];
     if (ta->frozen > 0) {
-      cx.grid[(int)actor->r * cx.W + actor->c] = MG_CELL(MG_CELL_AGENT, ti);
-      cx.grid[tr * cx.W + tc] = MG_CELL(MG_CELL_AGENT, ai);
+      cx.grid[(int)actor->r * cx.W + actor->c] = cx.cc.agent(ti);
+      cx.grid[tr * cx.W + tc] = cx.cc.agent(ai);
       ta->r = actor->r;
       ta->c = actor->c;
       actor->r = (uint16_t)tr;
@@ -627,7 +644,7 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
     }
     return false;  // Agent::onUse (agent.cpp:179-185)
   }
-  if (kind == MG_CELL_ASSEMBLER) return mg_assembler_use(cx, ai, target & MG_IDX_MASK);
+  if (kind == MG_CELL_ASSEMBLER) return mg_assembler_use(cx, ai, cx.cc.asm_idx(target));
   return false;  // walls are not Usable
 }
 
@@ -754,193 +771,77 @@ __device__ __forceinline__ int mg_inv_ntok(int amount, int base, int n_inv_token
   return n;
 }
 
-struct TokOut {  // writes (loc, feature, value) triples into an LDS row, dropping tokens past the budget
-  uint8_t* row;
-  int T, pos;
-  uint8_t loc;
-  __device__ __forceinline__ void put(int f, int v) {
-    if (pos < T) {
-      row[pos * 3 + 0] = loc;
-      row[pos * 3 + 1] = (uint8_t)f;
-      row[pos * 3 + 2] = (uint8_t)v;
-    }
-    pos++;
-  }
+// Token sinks: (feature, value) pairs of one object.
+struct PairOut {  // into an LDS token list of uint16 (feature | value << 8)
+  uint16_t* dst;
+  int n;
+  __device__ __forceinline__ void put(int f, int v) { dst[n++] = (uint16_t)((f & 0xFF) | ((v & 0xFF) << 8)); }
+};
+struct CountOut {
+  int n;
+  __device__ __forceinline__ void put(int, int) { n++; }
 };
 
-// Count (emit == false) or write (emit == true) the tokens of the object in cell `cv`
-// (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578).
-template <bool EMIT>
-__device__ inline int mg_object_tokens(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
-                                       const int4* asm_info, int H, int W, uint32_t step, uint16_t cv, TokOut* out) {
-  int kind = cv >> MG_KIND_SHIFT, idx = cv & MG_IDX_MASK;
-  int n = 0;
+// The tokens an object shows to any observer (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578).  They do not
+// depend on who looks, so the observation kernel builds each object's list once per step.
+template <class OUT>
+__device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
+                                        const int4* asm_info, CellCodec cc, int H, int W, uint32_t step, uint16_t cv,
+                                        OUT& out) {
+  int kind = cc.kind(cv);
   const int f_tag = dc[DC_FID0 + MG_F_TAG], f_vibe = dc[DC_FID0 + MG_F_VIBE];
   if (kind == MG_CELL_WALL) {
-    const int* rec = wall_rec(dc, idx);
+    const int* rec = wall_rec(dc, cc.wall_idx(cv));
     int ot = rec[WR_OFF_TAGS], nt = L_n(dc, ot);
-    if (EMIT)
-      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
-    n += nt;
-    if (rec[WR_VIBE] != 0) {
-      if (EMIT) out->put(f_vibe, rec[WR_VIBE]);
-      n++;
-    }
+    for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
+    if (rec[WR_VIBE] != 0) out.put(f_vibe, rec[WR_VIBE]);
   } else if (kind == MG_CELL_AGENT) {
-    const DAgent* a = &ag[idx];
+    const DAgent* a = &ag[cc.agent_idx(cv)];
     const int* gr = group_rec(dc, a->group);
     int base = dc[DC_TOKEN_BASE], nit = dc[DC_N_INV_TOKENS], ofi = dc[DC_OFF_FID_INV];
-    if (EMIT) {
-      out->put(dc[DC_FID0 + MG_F_GROUP], gr[GR_GROUP_ID]);
-      out->put(dc[DC_FID0 + MG_F_FROZEN], a->frozen != 0 ? 1 : 0);
-      if (a->vibe != 0) out->put(f_vibe, a->vibe);
-    }
-    n += 2 + (a->vibe != 0 ? 1 : 0);
+    out.put(dc[DC_FID0 + MG_F_GROUP], gr[GR_GROUP_ID]);
+    out.put(dc[DC_FID0 + MG_F_FROZEN], a->frozen != 0 ? 1 : 0);
+    if (a->vibe != 0) out.put(f_vibe, a->vibe);
     int ni = a->n_items;
-    for (int i = 0; i < ni; i++) {
+    for (int i = 0; i < ni; i++) {  // observation_encoder.hpp:165-180
       int item = a->order[i], amount = a->amt[item];
-      if (EMIT) {
-        out->put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
-        unsigned rem = (unsigned)amount / (unsigned)base;
-        for (int p = 1; p < nit && rem > 0; p++) {
-          out->put(dc[ofi + item * nit + p], rem % (unsigned)base);
-          rem /= (unsigned)base;
-        }
+      out.put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
+      unsigned rem = (unsigned)amount / (unsigned)base;
+      for (int p = 1; p < nit && rem > 0; p++) {
+        out.put(dc[ofi + item * nit + p], rem % (unsigned)base);
+        rem /= (unsigned)base;
       }
-      n += mg_inv_ntok(amount, base, nit);
     }
     int ot = gr[GR_OFF_TAGS], nt = L_n(dc, ot);
-    if (EMIT)
-      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
-    n += nt;
+    for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
   } else if (kind == MG_CELL_ASSEMBLER) {
+    int idx = cc.asm_idx(cv);
     const DAsm* s = &as[idx];
     int4 info = asm_info[idx];
     const int* rec = asm_rec(dc, info.z);
     uint32_t remaining = s->cooldown_end <= step ? 0 : s->cooldown_end - step;
     if (remaining > 255u) remaining = 255u;
-    if (remaining > 0) {
-      if (EMIT) out->put(dc[DC_FID0 + MG_F_COOLDOWN], (int)remaining);
-      n++;
-    }
-    if (s->clipped) {
-      if (EMIT) out->put(dc[DC_FID0 + MG_F_CLIPPED], 1);
-      n++;
-    }
+    if (remaining > 0) out.put(dc[DC_FID0 + MG_F_COOLDOWN], (int)remaining);
+    if (s->clipped) out.put(dc[DC_FID0 + MG_F_CLIPPED], 1);
     uint32_t max_uses = (uint32_t)rec[AR_MAX_USES];
     if (max_uses > 0) {
       uint32_t ru = s->uses_count < max_uses ? max_uses - s->uses_count : 0;
       if (ru > 255u) ru = 255u;
-      if (EMIT) out->put(dc[DC_FID0 + MG_F_REMAINING_USES], (int)ru);
-      n++;
+      out.put(dc[DC_FID0 + MG_F_REMAINING_USES], (int)ru);
     }
     if (dc[DC_PROTO_OBS]) {
-      int po = mg_current_protocol(dc, grid, ag, H, W, info.x, info.y, info.z, s->clipped != 0);
+      int po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, s->clipped != 0);
       if (po >= 0) {
         int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
         for (int i = 0; i < ni; i++)
-          if (KV_v(dc, oi, i) > 0) {
-            if (EMIT) out->put(dc[dc[DC_OFF_FID_IN] + KV_k(dc, oi, i)], KV_v(dc, oi, i));
-            n++;
-          }
+          if (KV_v(dc, oi, i) > 0) out.put(dc[dc[DC_OFF_FID_IN] + KV_k(dc, oi, i)], KV_v(dc, oi, i));
         int oo = dc[po + PR_OFF_OUT], no = L_n(dc, oo);
         for (int i = 0; i < no; i++)
-          if (KV_v(dc, oo, i) > 0) {
-            if (EMIT) out->put(dc[dc[DC_OFF_FID_OUT] + KV_k(dc, oo, i)], KV_v(dc, oo, i));
-            n++;
-          }
+          if (KV_v(dc, oo, i) > 0) out.put(dc[dc[DC_OFF_FID_OUT] + KV_k(dc, oo, i)], KV_v(dc, oo, i));
       }
     }
     int ot = rec[AR_OFF_TAGS], nt = L_n(dc, ot);
-    if (EMIT)
-      for (int i = 0; i < nt; i++) out->put(f_tag, L_at(dc, ot, i));
-    n += nt;
-    if (rec[AR_VIBE] != 0) {
-      if (EMIT) out->put(f_vibe, rec[AR_VIBE]);
-      n++;
-    }
+    for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
+    if (rec[AR_VIBE] != 0) out.put(f_vibe, rec[AR_VIBE]);
   }
-  return n;
-}
-
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  *total = __shfl(x, 63, 64);
-  return x - v;
-}
-
-// One agent's observation row, encoded by one wave into `row` (LDS, T*3 bytes, pre-filled with 0xFF).
-// MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns attempted token count.
-__device__ inline int mg_encode_agent(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
-                                      const int4* asm_info, int H, int W, uint32_t step, int ai, int action,
-                                      uint8_t* row, int lane) {
-  const DAgent* me = &ag[ai];
-  const int T = dc[DC_T], oh = dc[DC_OBS_H], ow = dc[DC_OBS_W];
-  const int hr = oh >> 1, wr = ow >> 1;
-  const int ar = me->r, ac = me->c;
-  int base = 0;
-  {
-    // global tokens + compass: a handful of tokens, written by lane 0
-    TokOut o{row, T, 0, (uint8_t)((hr << 4) | (wr & 0x0F))};
-    if (dc[DC_G_COMPLETION]) {
-      int pct = 0, ms = dc[DC_MAX_STEPS];
-      if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
-      if (lane == 0) o.put(dc[DC_FID0 + MG_F_COMPLETION], pct); else o.pos++;
-    }
-    if (dc[DC_G_LAST_ACTION]) {
-      if (lane == 0) o.put(dc[DC_FID0 + MG_F_LAST_ACTION], action); else o.pos++;
-    }
-    if (dc[DC_G_LAST_REWARD]) {
-      // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
-      if (lane == 0) o.put(dc[DC_FID0 + MG_F_LAST_REWARD], 0); else o.pos++;
-    }
-    if (dc[DC_G_GOAL]) {
-      const int* gr = group_rec(dc, me->group);
-      int og = gr[GR_OFF_GOAL], ng = L_n(dc, og);
-      for (int i = 0; i < ng; i++) {
-        if (lane == 0) o.put(dc[DC_FID0 + MG_F_GOAL], L_at(dc, og, i)); else o.pos++;
-      }
-    }
-    if (dc[DC_G_COMPASS]) {
-      int dr = H / 2 - ar, dcc = W / 2 - ac;
-      int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
-      if (sr != 0 || sc != 0) {
-        int orr = hr + sr, occ = wr + sc;
-        if (orr >= 0 && orr < oh && occ >= 0 && occ < ow) {
-          o.loc = (uint8_t)((orr << 4) | (occ & 0x0F));
-          if (lane == 0) o.put(dc[DC_FID0 + MG_F_COMPASS], 1); else o.pos++;
-        }
-      }
-    }
-    base = o.pos;
-  }
-  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN];
-  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
-  const int r_end = min(ar + hr + 1, H), c_end = min(ac + wr + 1, W);
-  for (int p0 = 0; p0 < P; p0 += 64) {
-    int p = p0 + lane;
-    uint16_t cv = 0;
-    int r = 0, c = 0;
-    if (p < P) {
-      int packed = dc[op + p];
-      r = ar + (packed & 0xFF) - 8;
-      c = ac + ((packed >> 8) & 0xFF) - 8;
-      if (r >= r_start && r < r_end && c >= c_start && c < c_end) cv = grid[r * W + c];
-    }
-    int n = 0;
-    if (cv != 0) n = mg_object_tokens<false>(dc, grid, ag, as, asm_info, H, W, step, cv, nullptr);
-    int total;
-    int off = base + wave_excl_scan(n, lane, &total);
-    if (n > 0 && off < T) {
-      TokOut o{row, T, off, (uint8_t)(((r - ar + hr) << 4) | ((c - ac + wr) & 0x0F))};
-      mg_object_tokens<true>(dc, grid, ag, as, asm_info, H, W, step, cv, &o);
-    }
-    base += total;
-  }
-  return base;
 }
