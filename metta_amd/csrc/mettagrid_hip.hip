@@ -62,6 +62,18 @@ struct KArgs {
   float* ep_rewards;
   uint8_t* success;
   int* exec;  // [E][A] executed action of this step (last_action token)
+  uint32_t* mode;  // [E] fast path hand-off: 0 = step done, 1 | n << 8 = n pending assembler uses, 2 = general path
+  uint8_t* pend;   // [E][A][32] pending assembler uses (fast path -> general kernel)
+  int fast;        // fast (wave-parallel) act kernel in use
+  // Episode-start templates, one per map (built once by mg_set_maps with the reset kernel): restarting an
+  // environment inside a step is a handful of coalesced copies.
+  const DAgent* t_agents;     // [P][A]
+  const DAsm* t_asms;         // [P][NAmax]
+  const float* t_astats;      // [P][A][SA]
+  const uint32_t* t_atouched; // [P][A][TW]
+  const float* t_gstats;      // [P][SG]
+  const uint32_t* t_gtouched; // [P][GW]
+  uint32_t* mt_init;          // [E][624] std::mt19937(seed) state of each env's seed
   int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
   int auto_reset, map_stride;
   const int* reset_envs;  // reset kernel only
@@ -74,7 +86,6 @@ struct Lds {
   uint16_t* grid;
   DAgent* ag;
   DAsm* as;
-  int* sd;
   int* gd;
   uint32_t* dirty_amt;
   uint32_t* dirty_misc;
@@ -104,13 +115,13 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   size_t dco = take((size_t)dcw * 4);
   if (l) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
-  size_t sd = take((size_t)A * SA * 4), gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take(nwaves ? (size_t)NOBJ : 0), hp = take(nwaves ? (size_t)NOBJ * TS * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
   if (l) {
     l->ocnt = (uint8_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
-    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->sd = (int*)(base + sd);
+    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
     l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
@@ -337,7 +348,6 @@ __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e
     if (i < nasm) s.clipped = (uint32_t)asm_rec(dc, asm_info[i].z)[AR_START_CLIPPED];
     l.as[i] = s;
   }
-  for (int i = tid; i < a.A * a.SA; i += nt) l.sd[i] = 0;
   for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
   for (int i = tid; i < a.A; i += nt) {
     l.dirty_amt[i] = 0;
@@ -375,11 +385,14 @@ __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e
     l.tokacc[0] = l.tokacc[1] = l.tokacc[2] = 0.f;
     // std::mt19937(seed): mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i
     uint32_t* mt = a.mt + (size_t)e * 624;
+    uint32_t* mi = a.mt_init ? a.mt_init + (size_t)e * 624 : mt;
     uint32_t x = seed;
     mt[0] = x;
+    mi[0] = x;
     for (int i = 1; i < 624; i++) {
       x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
       mt[i] = x;
+      mi[i] = x;
     }
   }
   // populate_initial_inventory (agent.cpp:48-52): ignore_limits, stat hooks fire; one thread per agent
@@ -396,14 +409,6 @@ __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e
 __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& cx, int e, int tid, int nt) {
   float* as_ = a.astats + (size_t)e * a.A * a.SA;
   uint32_t* at_ = a.atouched + (size_t)e * a.A * a.TW;
-  for (int i = tid; i < a.A * a.SA; i += nt) {
-    int v = l.sd[i];
-    if (v != 0) {
-      int ai = i / a.SA, s = i - ai * a.SA;
-      as_[i] += (float)v;
-      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
-    }
-  }
   for (int ai = tid; ai < a.A; ai += nt) {
     uint32_t m = l.dirty_amt[ai];
     while (m) {
@@ -502,13 +507,15 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
   }
 }
 
-__device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int map_id, uint32_t step) {
+__device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e, int map_id, uint32_t step) {
   cx.dc = a.dc;
   cx.grid = l.grid;
   cx.ag = l.ag;
   cx.as = l.as;
   cx.asm_info = a.map_asm + (size_t)map_id * a.NAmax;
-  cx.sd = l.sd;
+  cx.astats = a.astats + (size_t)e * a.A * a.SA;
+  cx.atouched = a.atouched + (size_t)e * a.A * a.TW;
+  cx.TW = a.TW;
   cx.gd = l.gd;
   cx.dirty_amt = l.dirty_amt;
   cx.dirty_misc = l.dirty_misc;
@@ -619,6 +626,391 @@ __device__ inline int mg_count_agent_tokens(const KArgs& a, const Lds& l, const 
   return n;
 }
 
+// Restart a finished environment from the per-map templates (MettaGridPufferEnv.step -> _new_sim(),
+// mettagrid_puffer_env.py:158-164; same seed, next map).  All threads of the workgroup; HBM state only.
+__device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid, int nt) {
+  mg_snapshot_finished(a, e, env.step, tid, nt);
+  __syncthreads();
+  const int m = (int)(((int)env.map_id + a.map_stride) % a.P);
+  env.map_id = (uint32_t)m;
+  env.episodes += 1;
+  env.step = 0;
+  env.mt_idx = 624;
+  env.done = 0;
+  env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
+  {
+    const uint4* s = (const uint4*)(a.t_agents + (size_t)m * a.A);
+    uint4* d = (uint4*)(a.agents + (size_t)e * a.A);
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) d[i] = s[i];
+  }
+  {
+    const uint4* s = (const uint4*)(a.t_asms + (size_t)m * a.NAmax);
+    uint4* d = (uint4*)(a.asms + (size_t)e * a.NAmax);
+    for (int i = tid; i < a.NAmax; i += nt) d[i] = s[i];
+  }
+  {
+    const float* s = a.t_astats + (size_t)m * a.A * a.SA;
+    float* d = a.astats + (size_t)e * a.A * a.SA;
+    for (int i = tid; i < a.A * a.SA; i += nt) d[i] = s[i];
+    const uint32_t* st = a.t_atouched + (size_t)m * a.A * a.TW;
+    uint32_t* dt = a.atouched + (size_t)e * a.A * a.TW;
+    for (int i = tid; i < a.A * a.TW; i += nt) dt[i] = st[i];
+    const float* sg = a.t_gstats + (size_t)m * a.SG;
+    float* dg = a.gstats + (size_t)e * a.SG;
+    for (int i = tid; i < a.SG; i += nt) dg[i] = sg[i];
+    const uint32_t* sgt = a.t_gtouched + (size_t)m * a.GW;
+    uint32_t* dgt = a.gtouched + (size_t)e * a.GW;
+    for (int i = tid; i < a.GW; i += nt) dgt[i] = sgt[i];
+  }
+  {
+    const uint32_t* s = a.mt_init + (size_t)e * 624;
+    uint32_t* d = a.mt + (size_t)e * 624;
+    for (int i = tid; i < 624; i += nt) d[i] = s[i];
+  }
+  for (int i = tid; i < a.A; i += nt) {
+    size_t g = (size_t)e * a.A + i;
+    a.rewards[g] = 0.f;
+    a.ep_rewards[g] = 0.f;
+    a.term[g] = 0;
+    a.trunc[g] = 0;
+    a.success[g] = 0;
+  }
+  __threadfence();
+  __syncthreads();
+}
+
+// Assembler uses handed over by the fast act kernel, in action order, on LDS-staged agent/assembler records.
+__device__ inline void mg_pending_uses(const KArgs& a, const Lds& l, Ctx& cx, int e, const DEnv& env, int count, int tid,
+                                       int nt) {
+  const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
+  uint4* dst = (uint4*)l.ag;
+  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+  const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
+  uint4* d2 = (uint4*)l.as;
+  for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+  for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  for (int i = tid; i < a.A; i += nt) {
+    l.dirty_amt[i] = 0;
+    l.dirty_misc[i] = 0;
+  }
+  mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);  // env.step was already advanced by the fast kernel
+  cx.grid = nullptr;
+  __syncthreads();
+  if (tid == 0) {
+    const uint8_t* rec = a.pend + (size_t)e * a.A * 32;
+    for (int q = 0; q < count; q++, rec += 32) {
+      int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
+      int act = (int)(rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((uint32_t)rec[7] << 24));
+      int near[8];
+      uint8_t vibes[8];
+      for (int i = 0; i < 8; i++) {
+        near[i] = rec[8 + i];
+        vibes[i] = rec[16 + i];
+      }
+      bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
+      if (ok) {
+        l.ag[actor].succ[MG_ACT_MOVE] += 1;
+        a.exec[(size_t)e * a.A + actor] = act;
+        a.success[(size_t)e * a.A + actor] = 1;
+      } else {
+        l.ag[actor].fail[MG_ACT_MOVE] += 1;
+      }
+    }
+    l.flags[2] = cx.asm_dirty;
+  }
+  __syncthreads();
+  mg_flush_stats(a, l, cx, e, tid, nt);
+  uint4* wd = (uint4*)(a.agents + (size_t)e * a.A);
+  const uint4* ws = (const uint4*)l.ag;
+  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) wd[i] = ws[i];
+  if (l.flags[2]) {
+    uint4* wd2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
+    const uint4* ws2 = (const uint4*)l.as;
+    for (int i = tid; i < a.NAmax; i += nt) wd2[i] = ws2[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// kernel 1 (fast path): actions, wave-parallel.  One wave per environment, lane i = agent i.
+//
+// Eligible configurations (host-checked): no vibe-triggered attack/transfer, no required/consumed resources on
+// noop/move/change_vibe, no inventory regeneration, A <= 64.  Then within a step positions change only through
+// moves into empty cells, and the reference's shuffled sequential loop (bindings/mettagrid_c.cpp:588-622) is
+// reproduced exactly by
+//   1. the std::shuffle ranks, from the same MT19937 draws (lanes hold draws; swaps applied to ranks),
+//   2. a fixed-point over "did agent j's move succeed", whose dependencies only point to lower ranks
+//      (unique solution; converges in a few ballots' worth of iterations),
+//   3. assembler uses (moves into an assembler), collected in rank order with the neighbour ring as it stood at
+//      that moment, and executed by the general kernel on LDS-staged inventories.
+// Environments that need anything else this step (episode restart, a frozen agent, a rejected RNG draw) are handed
+// to the general kernel whole (mode 2).
+// ------------------------------------------------------------------------------------------------------------
+#define MG_FAST_THREADS 64
+__global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
+  __shared__ uint32_t mtnext[624];
+  const int lane = threadIdx.x, e = blockIdx.x;
+  const int A = a.A, H = a.H, W = a.W;
+  const int* dc = a.dc;
+  DEnv env = a.env[e];
+  if (a.auto_reset && env.done) mg_restart_env(a, e, env, lane, 64);  // wave-uniform
+  const bool active = lane < A;
+  const size_t g = (size_t)e * A + (active ? lane : 0);
+  DAgent* rec = a.agents + g;
+  // agent fields this path touches
+  uint4 f0 = make_uint4(0, 0, 0, 0);
+  uint32_t max_swm = 0, succ0 = 0, succ1 = 0, succ2 = 0, fail0 = 0, fail1 = 0, fail2 = 0;
+  int act = 0;
+  if (active) {
+    f0 = *(const uint4*)rec;
+    max_swm = rec->max_swm;
+    succ0 = rec->succ[0]; succ1 = rec->succ[1]; succ2 = rec->succ[2];
+    fail0 = rec->fail[0]; fail1 = rec->fail[1]; fail2 = rec->fail[2];
+    act = a.actions[g];
+  }
+  int r = (int)(f0.x & 0xFFFF), c = (int)(f0.x >> 16);
+  int frozen = (int)(int16_t)(f0.z & 0xFFFF);
+  uint32_t vibe = (f0.z >> 16) & 0xFF, group = f0.z >> 24, swm = f0.w;
+  const bool any_frozen = __ballot(active && frozen != 0) != 0;
+  if (any_frozen) {  // wave-uniform; cannot arise in eligible configurations, kept as a guard
+    if (lane == 0) {
+      a.env[e] = env;
+      a.mode[e] = 2;
+    }
+    return;
+  }
+
+  // ---- MT19937 window -------------------------------------------------------------------
+  const uint32_t* mt = a.mt + (size_t)e * 624;
+  const int NW_ = a.NWIN < 64 ? a.NWIN : 64;
+  const bool need_twist = (int)env.mt_idx + NW_ > 624;
+  if (need_twist) {
+    for (int i = lane; i < 227; i += 64) mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+    __syncthreads();
+    for (int i = 227 + lane; i < 454; i += 64) mtnext[i] = mt_mix(mt[i], mt[i + 1], mtnext[i - 227]);
+    __syncthreads();
+    for (int i = 454 + lane; i < 623; i += 64) mtnext[i] = mt_mix(mt[i], mt[i + 1], mtnext[i - 227]);
+    __syncthreads();
+    if (lane == 0) mtnext[623] = mt_mix(mt[623], mtnext[0], mtnext[396]);
+    __syncthreads();
+  }
+  uint32_t w = 0;
+  if (lane < NW_) {
+    int j = (int)env.mt_idx + lane;
+    w = mt_temper(j < 624 ? mt[j] : mtnext[j - 624]);
+  }
+  // draw t of std::shuffle(iota(A)): t = 0 -> U(2) when A is even; then positions i = i0 + 2(t - t0), range (i+1)(i+2)
+  const int even = (A & 1) == 0 ? 1 : 0;
+  const int D = A <= 1 ? 0 : even + (A - (even ? 2 : 1)) / 2;
+  uint32_t val = 0;
+  bool reject = false;
+  if (lane < D) {
+    uint32_t range;
+    if (even && lane == 0) {
+      range = 2;
+    } else {
+      uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (lane - even));
+      range = (i + 1) * (i + 2);
+    }
+    unsigned long long product = (unsigned long long)w * range;
+    uint32_t low = (uint32_t)product;
+    reject = low < range && low < (0u - range) % range;  // Lemire rejection: extremely rare, needs a serial redraw
+    val = (uint32_t)(product >> 32);
+  }
+  if (__ballot(reject) != 0) {
+    if (lane == 0) {
+      a.env[e] = env;  // keep a restart done above
+      a.mode[e] = 2;
+    }
+    return;
+  }
+  // ranks: agent x sits at position rank_x of the shuffled order; a swap of positions (p, q) exchanges the ranks
+  int rank = lane;
+  for (int t = 0; t < D; t++) {
+    uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)val, t);
+    if (even && t == 0) {
+      int j = (int)x;  // swap(v[1], v[j])
+      rank = rank == 1 ? j : (rank == j ? 1 : rank);
+    } else {
+      int i = (even ? 2 : 1) + 2 * (t - even);
+      int s = i + 1;
+      int pa = (int)(x / (uint32_t)(s + 1)), pb = (int)(x % (uint32_t)(s + 1));
+      rank = rank == i ? pa : (rank == pa ? i : rank);
+      rank = rank == i + 1 ? pb : (rank == pb ? i + 1 : rank);
+    }
+  }
+
+  // ---- decode actions ------------------------------------------------------------------------------------
+  const int n_actions = dc[DC_N_ACTIONS], oa = dc[DC_OFF_ACTIONS];
+  const bool valid = active && act >= 0 && act < n_actions;
+  int kind = -1, arg = 0;
+  if (valid) {
+    kind = dc[oa + 2 * act];
+    arg = dc[oa + 2 * act + 1];
+  }
+  const bool is_move = valid && kind == MG_ACT_MOVE;
+  const bool is_vibe = valid && kind == MG_ACT_CHANGE_VIBE;
+  int tr = r, tc = c;
+  uint16_t scell = 0;
+  bool inb = false;
+  if (is_move) {
+    // deltas of orientation.hpp:26-48: N S W E NW NE SW SE
+    const int dx = (arg == 2 || arg == 4 || arg == 6) ? -1 : ((arg == 3 || arg == 5 || arg == 7) ? 1 : 0);
+    const int dy = (arg == 0 || arg == 4 || arg == 5) ? -1 : ((arg == 1 || arg == 6 || arg == 7) ? 1 : 0);
+    tr = r + dy;
+    tc = c + dx;
+    inb = tr >= 0 && tc >= 0 && tr < H && tc < W;
+    if (inb) scell = a.map_cells[(size_t)env.map_id * a.HW + tr * W + tc];
+  }
+  const CellCodec cc{a.NW, A};
+  const int skind = cc.kind(scell);
+  const bool mover = is_move && inb && skind == MG_CELL_EMPTY;
+  const bool user = is_move && inb && skind == MG_CELL_ASSEMBLER;
+  const uint32_t P = ((uint32_t)r << 16) | (uint32_t)c;
+  const uint32_t Tm = mover ? (((uint32_t)tr << 16) | (uint32_t)tc) : 0xFFFFFFFFu;
+
+  // ---- fixed point over move success ----------------------------------------------------------------------
+  bool m = mover;
+  for (int it = 0; it <= A; it++) {
+    unsigned long long mm = __ballot(m);
+    bool blocked = false;
+    for (int j = 0; j < A; j++) {
+      uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
+      uint32_t Tj = (uint32_t)__builtin_amdgcn_readlane((int)Tm, j);
+      int rj = __builtin_amdgcn_readlane(rank, j);
+      bool mj = (mm >> j) & 1ull;
+      bool left_before = rj < rank && mj;          // j moved away before my turn
+      bool came_before = rj < rank && mj;          // j moved in before my turn
+      if (j != lane) blocked |= (Pj == Tm && !left_before) || (Tj == Tm && came_before);
+    }
+    bool nm = mover && !blocked;
+    bool changed = nm != m;
+    m = nm;
+    if (__ballot(changed) == 0) break;
+  }
+  const unsigned long long moved_mask = __ballot(m);
+
+  // ---- assembler uses, in rank order, with the ring as it stood at that moment ------------------------------
+  unsigned long long umask = __ballot(user);
+  int n_pending = 0;
+  uint8_t* pend = a.pend + (size_t)e * A * 32;
+  while (umask) {
+    // next user = lowest rank among the remaining ones
+    int best = -1, best_rank = 1 << 30;
+    unsigned long long scan = umask;
+    while (scan) {
+      int j = __ffsll((long long)scan) - 1;
+      scan &= scan - 1;
+      int rj = __builtin_amdgcn_readlane(rank, j);
+      if (rj < best_rank) {
+        best_rank = rj;
+        best = j;
+      }
+    }
+    umask &= ~(1ull << best);
+    const int k = best_rank;
+    const int ar = __builtin_amdgcn_readlane(tr, best), ac = __builtin_amdgcn_readlane(tc, best);
+    const int asm_cell = __builtin_amdgcn_readlane((int)scell, best);
+    const int uact = __builtin_amdgcn_readlane(act, best);
+    // my position and vibe at time k
+    const bool before = rank < k;
+    const int pr = (before && m) ? tr : r, pc = (before && m) ? tc : c;
+    const uint32_t vk = (before && is_vibe) ? (uint32_t)arg : vibe;
+    const int dr = pr - ar, dcl = pc - ac;
+    const bool adj = active && dr >= -1 && dr <= 1 && dcl >= -1 && dcl <= 1 && !(dr == 0 && dcl == 0);
+    // ring index among the in-map neighbour cells (NW, N, NE, W, E, SW, S, SE)
+    uint32_t vmask8 = 0;
+    for (int q = 0; q < 8; q++) {
+      int o9 = q < 4 ? q : q + 1;
+      int rr = ar + o9 / 3 - 1, c2 = ac + o9 % 3 - 1;
+      if (rr >= 0 && c2 >= 0 && rr < H && c2 < W) vmask8 |= 1u << q;
+    }
+    const int np = __popc(vmask8);
+    int o9m = (dr + 1) * 3 + (dcl + 1);
+    int om = o9m < 4 ? o9m : o9m - 1;
+    int posidx = adj ? __popc(vmask8 & ((1u << om) - 1u)) : 0;
+    const int start = __builtin_amdgcn_readlane(posidx, best);  // the actor is adjacent by construction
+    int key = adj ? (posidx - start + np) % np : -1;
+    // emit the record: neighbours in key order
+    uint8_t* rec8 = pend + (size_t)n_pending * 32;
+    int nn = 0;
+    for (int q = 0; q < np; q++) {
+      unsigned long long sel = __ballot(adj && key == q);
+      if (sel) {
+        int j = __ffsll((long long)sel) - 1;
+        uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)vk, j);
+        if (lane == 0) {
+          rec8[8 + nn] = (uint8_t)j;
+          rec8[16 + nn] = (uint8_t)vj;
+        }
+        nn++;
+      }
+    }
+    if (lane == 0) {
+      rec8[0] = (uint8_t)best;
+      rec8[1] = (uint8_t)nn;
+      int ai_ = cc.asm_idx((uint16_t)asm_cell);
+      rec8[2] = (uint8_t)(ai_ & 0xFF);
+      rec8[3] = (uint8_t)(ai_ >> 8);
+      rec8[4] = (uint8_t)(uact & 0xFF);
+      rec8[5] = (uint8_t)((uact >> 8) & 0xFF);
+      rec8[6] = (uint8_t)((uact >> 16) & 0xFF);
+      rec8[7] = (uint8_t)((uact >> 24) & 0xFF);
+    }
+    n_pending++;
+  }
+  (void)moved_mask;
+  (void)group;
+
+  // ---- per-agent bookkeeping (action_handler.hpp:118-150) ----------------------------------------------------
+  if (active) {
+    bool ok = false;
+    if (valid) {
+      if (kind == MG_ACT_NOOP) ok = true;
+      else if (is_vibe) { vibe = (uint32_t)arg; ok = true; }
+      else if (mover) ok = m;
+      // users: decided by the general kernel; static failures (wall / outside): false
+      if (m) { r = tr; c = tc; swm = 0; }
+      else { swm += 1; if (swm > max_swm) max_swm = swm; }
+      if (!user) {
+        if (ok) { if (kind == 0) succ0++; else if (kind == 1) succ1++; else succ2++; }
+        else { if (kind == 0) fail0++; else if (kind == 1) fail1++; else fail2++; }
+      }
+      // prev_location = location
+      f0.x = ((uint32_t)c << 16) | (uint32_t)r;
+      f0.y = f0.x;
+      f0.z = (f0.z & 0xFF00FFFFu) | (vibe << 16);
+      f0.w = swm;
+      *(uint4*)rec = f0;
+      rec->max_swm = max_swm;
+      rec->succ[0] = succ0; rec->succ[1] = succ1; rec->succ[2] = succ2;
+      rec->fail[0] = fail0; rec->fail[1] = fail1; rec->fail[2] = fail2;
+    } else {
+      // _handle_invalid_action, once per priority level (bindings/mettagrid_c.cpp:565-570,599-608)
+      const MgAgentSlots AS{a.R, a.NG};
+      const int passes = dc[DC_MAX_PRIORITY] + 1;
+      float* row = a.astats + g * a.SA;
+      int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
+      row[AS.invalid()] += (float)passes;
+      row[AS.invalid_variant(variant)] += (float)passes;
+    }
+    a.exec[g] = ok ? act : 0;
+    a.success[g] = ok ? 1 : 0;
+  }
+  // ---- env write-back ------------------------------------------------------------------------------------------
+  uint32_t new_idx = env.mt_idx + (uint32_t)D;
+  if (new_idx > 624) {
+    uint32_t* mtw = a.mt + (size_t)e * 624;
+    for (int i = lane; i < 624; i += 64) mtw[i] = mtnext[i];
+    new_idx -= 624;
+  }
+  if (lane == 0) {
+    env.step += 1;
+    env.mt_idx = new_idx;
+    a.env[e] = env;
+    a.mode[e] = n_pending > 0 ? (1u | ((uint32_t)n_pending << 8)) : 0u;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // kernel 1: actions.  One wave per environment; thread 0 resolves the actions in the reference's shuffled
 // sequential order on LDS state (bindings/mettagrid_c.cpp:572-650).
@@ -630,6 +1022,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
   Lds l;
   mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
+  if (a.fast && a.mode[e] == 0) return;  // the fast kernel finished this environment's step
   if (DCL) {
     for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
     a.dc = l.dc;
@@ -639,54 +1032,35 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   const int* dc = a.dc;
   Ctx cx;
 
-  const bool do_reset = a.auto_reset && env.done;  // block-uniform
-  if (do_reset) {
-    // MettaGridPufferEnv.step: `if terminals.all() or truncations.all(): self._new_sim()` before stepping
-    mg_snapshot_finished(a, e, env.step, tid, nt);
-    __syncthreads();
-    env.map_id = (uint32_t)(((int)env.map_id + a.map_stride) % a.P);
-    env.episodes += 1;
-    env.step = 0;
-    env.mt_idx = 624;
-    env.done = 0;
-    env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
-    mg_make_ctx(a, l, cx, (int)env.map_id, 0);
-    mg_load_grid(a, l, (int)env.map_id, tid, nt);
-    mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
-    mg_overlay_agents(a, l, tid, nt);
-    __syncthreads();
-    const int4* asm_info = a.map_asm + (size_t)env.map_id * a.NAmax;
-    for (int ai = tid; ai < a.A; ai += nt) l.tok_att[ai] = mg_count_agent_tokens(a, l, asm_info, ai);
-    __syncthreads();
-    if (tid == 0) {
-      mg_token_stats(a, l, dc[DC_INIT_PASSES]);
-      float* gs_ = a.gstats + (size_t)e * a.SG;
-      gs_[0] = l.tokacc[0];
-      gs_[1] = l.tokacc[1];
-      gs_[2] = l.tokacc[2];
-      atomicOr(&a.gtouched[(size_t)e * a.GW], 7u);
+  if (a.fast) {
+    // Hand-off from mg_act_fast_kernel: nothing left, only assembler uses left, or the whole step.
+    uint32_t mode = a.mode[e];
+    if (mode == 0) return;
+    if ((mode & 0xFF) == 1) {
+      mg_pending_uses(a, l, cx, e, env, (int)(mode >> 8), tid, nt);
+      return;
     }
-    __syncthreads();
-  } else {
-    mg_load_grid(a, l, (int)env.map_id, tid, nt);
-    const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
-    uint4* dst = (uint4*)l.ag;
-    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
-    const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
-    uint4* d2 = (uint4*)l.as;
-    for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
-    for (int i = tid; i < a.A * a.SA; i += nt) l.sd[i] = 0;
-    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
-    for (int i = tid; i < a.A; i += nt) {
-      l.dirty_amt[i] = 0;
-      l.dirty_misc[i] = 0;
-    }
-    __syncthreads();
-    mg_overlay_agents(a, l, tid, nt);
   }
+
+  const bool do_reset = a.auto_reset && env.done;  // block-uniform
+  if (do_reset) mg_restart_env(a, e, env, tid, nt);
+  mg_load_grid(a, l, (int)env.map_id, tid, nt);
+  const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
+  uint4* dst = (uint4*)l.ag;
+  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+  const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
+  uint4* d2 = (uint4*)l.as;
+  for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  for (int i = tid; i < a.A; i += nt) {
+    l.dirty_amt[i] = 0;
+    l.dirty_misc[i] = 0;
+  }
+  __syncthreads();
+  mg_overlay_agents(a, l, tid, nt);
   mg_stage_rng(a, l, e, env.mt_idx, tid, nt);
   env.step += 1;
-  mg_make_ctx(a, l, cx, (int)env.map_id, env.step);
+  mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
   __syncthreads();
 
   if (tid == 0) {
@@ -702,10 +1076,9 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
       bool ok = false;
       if (act < 0 || act >= n_actions) {
         // _handle_invalid_action runs once per priority level (the check precedes the priority filter)
-        int* sda = l.sd + ai * a.SA;
-        sda[cx.AS.invalid()] += passes;
+        mg_stat_add(cx, ai, cx.AS.invalid(), passes);
         int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
-        sda[cx.AS.invalid_variant(variant)] += passes;
+        mg_stat_add(cx, ai, cx.AS.invalid_variant(variant), passes);
       } else {
         ok = mg_handle_action(cx, ai, dc[oa + 2 * act], dc[oa + 2 * act + 1]);
         if (ok) l.exec[ai] = act;
@@ -820,7 +1193,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   env.done = 0;
   env.error = 0;
   Ctx cx;
-  mg_make_ctx(a, l, cx, (int)env.map_id, 0);
+  mg_make_ctx(a, l, cx, e, (int)env.map_id, 0);
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
   mg_overlay_agents(a, l, tid, nt);
@@ -861,20 +1234,20 @@ __global__ void mg_end_episode_kernel(KArgs a, int env) {
 __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const int* items, const int* amounts) {
   extern __shared__ __align__(16) unsigned char smem[];
   if (threadIdx.x != 0) return;
-  // minimal LDS context: one agent record and one row of stat deltas
   DAgent* ag = (DAgent*)smem;
-  int* sd = (int*)(smem + mg_align16(sizeof(DAgent)));
-  uint32_t* dirty = (uint32_t*)(sd + a.SA);
+  uint32_t* dirty = (uint32_t*)(smem + mg_align16(sizeof(DAgent)));
   *ag = a.agents[(size_t)e * a.A + agent];
-  for (int i = 0; i < a.SA; i++) sd[i] = 0;
   dirty[0] = dirty[1] = 0;
   Ctx cx;
-  cx.dc = a.dc; cx.grid = nullptr; cx.ag = ag; cx.as = nullptr; cx.asm_info = nullptr; cx.sd = sd; cx.gd = nullptr;
+  cx.dc = a.dc; cx.grid = nullptr; cx.ag = ag; cx.as = nullptr; cx.asm_info = nullptr; cx.gd = nullptr;
+  cx.astats = a.astats + ((size_t)e * a.A + agent) * a.SA;  // record 0 of this context is `agent`
+  cx.atouched = a.atouched + ((size_t)e * a.A + agent) * a.TW;
+  cx.TW = a.TW;
   cx.dirty_amt = &dirty[0]; cx.dirty_misc = &dirty[1];
   cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
   cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A};
-  float* as_ = a.astats + ((size_t)e * a.A + agent) * a.SA;
-  uint32_t* at_ = a.atouched + ((size_t)e * a.A + agent) * a.TW;
+  float* as_ = cx.astats;
+  uint32_t* at_ = cx.atouched;
   uint8_t existing[MGD_MAX_R];
   int ne = ag->n_items;
   for (int i = 0; i < ne; i++) existing[i] = ag->order[i];
@@ -885,11 +1258,6 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
     zeroed |= 1u << item;  // stats.set(<item>.amount, 0)
   }
   for (int i = 0; i < n; i++) inv_update(cx, 0, items[i], amounts[i] - (int)ag->amt[items[i]]);
-  for (int s = 0; s < a.SA; s++)
-    if (sd[s] != 0) {
-      as_[s] += (float)sd[s];
-      atomicOr(&at_[s >> 5], 1u << (s & 31));
-    }
   uint32_t m = dirty[0] | zeroed;
   while (m) {
     int r = __ffs(m) - 1;
@@ -1000,6 +1368,15 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (c.A / 2 + 2 > 624) return fail("mg_create: too many agents for the RNG window");
   k.ROWB = (int)mg_align16((size_t)c.T * 3);
   k.auto_reset = 1; k.map_stride = 1;
+  {
+    // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
+    bool ok = c.A <= 64 && c.regen_interval == 0;
+    for (int v : c.vibe_handler) ok = ok && v == 0;
+    for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
+    const char* force = getenv("MG_FORCE_GENERAL");
+    if (force && force[0] == '1') ok = false;
+    k.fast = ok ? 1 : 0;
+  }
   std::vector<int32_t> dcfg = mg_build_dcfg(c);
   int* d_dc = nullptr;
   if (dalloc(h.get(), &d_dc, dcfg.size())) return 1;
@@ -1009,6 +1386,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   size_t N = (size_t)num_envs * c.A;
   if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
+  if (dalloc(h.get(), &k.mt_init, (size_t)num_envs * 624)) return 1;
   if (dalloc(h.get(), &k.agents, N)) return 1;
   if (dalloc(h.get(), &k.astats, N * k.SA)) return 1;
   if (dalloc(h.get(), &k.atouched, N * k.TW)) return 1;
@@ -1033,6 +1411,8 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &k.ep_rewards, N)) return 1;
   if (dalloc(h.get(), &k.success, N)) return 1;
   if (dalloc(h.get(), &k.exec, N)) return 1;
+  if (dalloc(h.get(), &k.mode, (size_t)num_envs)) return 1;
+  if (dalloc(h.get(), &k.pend, N * 32)) return 1;
   if (dalloc(h.get(), &h->d_list, (size_t)num_envs * 3)) return 1;
   if (dalloc(h.get(), &h->d_inv, (size_t)2 * MGD_MAX_R)) return 1;
   HIPCHK(hipMemset(k.obs, 0xFF, N * c.T * 3));
@@ -1156,6 +1536,61 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
     HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
   }
   HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // ---- episode-start templates: run the reset kernel once per map into template buffers ------------------
+  {
+    const size_t P = (size_t)num_maps, PA = P * c.A;
+    DAgent* t_agents; DAsm* t_asms; float* t_astats; uint32_t* t_atouched; float* t_gstats; uint32_t* t_gtouched;
+    if (dalloc(h, &t_agents, PA, true)) return 1;
+    if (dalloc(h, &t_asms, P * NAmax, true)) return 1;
+    if (dalloc(h, &t_astats, PA * k.SA, true)) return 1;
+    if (dalloc(h, &t_atouched, PA * k.TW, true)) return 1;
+    if (dalloc(h, &t_gstats, P * k.SG, true)) return 1;
+    if (dalloc(h, &t_gtouched, P * k.GW, true)) return 1;
+    std::vector<void*> tmp;
+    auto talloc = [&](size_t bytes) -> void* {
+      void* q = nullptr;
+      if (hipMalloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr;
+      (void)hipMemset(q, 0, bytes ? bytes : 1);
+      tmp.push_back(q);
+      return q;
+    };
+    KArgs kt = k;
+    kt.E = (int)P;
+    kt.env = (DEnv*)talloc(P * sizeof(DEnv));
+    kt.mt = (uint32_t*)talloc(P * 624 * 4);
+    kt.mt_init = nullptr;
+    kt.agents = t_agents; kt.asms = t_asms; kt.astats = t_astats; kt.atouched = t_atouched;
+    kt.gstats = t_gstats; kt.gtouched = t_gtouched;
+    kt.obs = (uint8_t*)talloc(PA * c.T * 3);
+    kt.rewards = (float*)talloc(PA * 4);
+    kt.ep_rewards = (float*)talloc(PA * 4);
+    kt.term = (uint8_t*)talloc(PA);
+    kt.trunc = (uint8_t*)talloc(PA);
+    kt.success = (uint8_t*)talloc(PA);
+    uint32_t* d_seeds = (uint32_t*)talloc(P * 4);
+    int* d_maps = (int*)talloc(P * 4);
+    bool okalloc = kt.env && kt.mt && kt.obs && kt.rewards && kt.ep_rewards && kt.term && kt.trunc && kt.success && d_seeds && d_maps;
+    int rc = 0;
+    if (!okalloc) {
+      rc = fail("mg_set_maps: out of device memory while building episode templates");
+    } else {
+      std::vector<int> iota((size_t)P);
+      for (size_t i = 0; i < P; i++) iota[i] = (int)i;
+      hipError_t e1 = hipMemcpy(d_maps, iota.data(), P * 4, hipMemcpyHostToDevice);
+      kt.reset_envs = nullptr;
+      kt.reset_seeds = d_seeds;
+      kt.reset_maps = d_maps;
+      hipLaunchKernelGGL(mg_reset_kernel, dim3((unsigned)P), dim3(MG_THREADS), h->lds_bytes, 0, kt);
+      hipError_t e2 = hipGetLastError();
+      hipError_t e3 = hipDeviceSynchronize();
+      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+        rc = fail(std::string("mg_set_maps: template build failed: ") + hipGetErrorString(e3 != hipSuccess ? e3 : (e2 != hipSuccess ? e2 : e1)));
+    }
+    for (void* q : tmp) (void)hipFree(q);
+    if (rc) return rc;
+    k.t_agents = t_agents; k.t_asms = t_asms; k.t_astats = t_astats; k.t_atouched = t_atouched;
+    k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
+  }
   h->maps_set = true;
   return 0;
 }
@@ -1200,6 +1635,7 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
     slot = h->ev_count;
     (void)hipEventRecord(h->ev[2 * slot], s);
   }
+  if (k.fast) hipLaunchKernelGGL(mg_act_fast_kernel, dim3((unsigned)h->E), dim3(MG_FAST_THREADS), 0, s, k);
   if (h->dc_lds) {
     hipLaunchKernelGGL(mg_act_kernel<true>, dim3((unsigned)h->E), dim3(MG_ACT_THREADS), h->lds_act, s, k);
     hipLaunchKernelGGL(mg_obs_kernel<true>, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_obs, s, k);
@@ -1393,7 +1829,7 @@ int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* ite
     HIPCHK(hipMemcpy(h->d_inv, items, (size_t)n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_inv + MGD_MAX_R, amounts, (size_t)n * 4, hipMemcpyHostToDevice));
   }
-  size_t lds = mg_align16(sizeof(DAgent)) + (size_t)h->k.SA * 4 + 16;
+  size_t lds = mg_align16(sizeof(DAgent)) + 16;
   hipLaunchKernelGGL(mg_set_inventory_kernel, dim3(1), dim3(64), lds, s, h->k, env, agent, n, h->d_inv, h->d_inv + MGD_MAX_R);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));

@@ -67,7 +67,9 @@ struct Ctx {
   DAgent* ag;
   DAsm* as;
   const int4* __restrict__ asm_info;  // per map: (r, c, cfg, obj_id)
-  int* sd;                            // [A][SA] agent stat deltas of this step
+  float* astats;                      // this env's [A][SA] stat slots in HBM (rare events add to them directly)
+  uint32_t* atouched;                 // this env's [A][TW] explicit touched bits
+  int TW;
   int* gd;                            // [SG] game stat deltas of this step
   uint32_t* dirty_amt;                // [A] bit r: <r>.amount was set this step
   uint32_t* dirty_misc;               // [A] bit0 diversity, bit1 max_steps_without_motion
@@ -78,6 +80,14 @@ struct Ctx {
   MgGameSlots GS;
   CellCodec cc;
 };
+
+// StatsTracker::add for the rarely touched per-agent keys (gained/lost, attack, transfer, swap, frozen ticks,
+// invalid index): fire-and-forget f32 atomic on the HBM slot.  Counts are small integers, so the sum is exact and
+// order independent.  The per-step hot counters live in the agent record instead (see DAgent).
+__device__ __forceinline__ void mg_stat_add(Ctx& cx, int ai, int slot, int delta) {
+  atomicAdd(&cx.astats[ai * cx.SA + slot], (float)delta);
+  atomicOr(&cx.atouched[ai * cx.TW + (slot >> 5)], 1u << (slot & 31));
+}
 
 // ---- small list helpers over the dcfg stream ----------------------------------------------------------------
 __device__ __forceinline__ int L_n(const int* dc, int off) { return dc[off]; }
@@ -182,11 +192,10 @@ __device__ inline int mg_free_space(const Ctx& cx, const DAgent* a, int item) {
 // Agent::on_inventory_change (agent.cpp:74-101)
 __device__ inline void mg_on_change(Ctx& cx, int ai, int item, int delta) {
   DAgent* a = &cx.ag[ai];
-  int* sd = cx.sd + ai * cx.SA;
   if (delta > 0)
-    sd[cx.AS.gained(item)] += delta;
+    mg_stat_add(cx, ai, cx.AS.gained(item), delta);
   else
-    sd[cx.AS.lost(item)] += -delta;
+    mg_stat_add(cx, ai, cx.AS.lost(item), -delta);
   cx.dirty_amt[ai] |= (1u << item);
   const int* gr = group_rec(cx.dc, a->group);
   if (gr[GR_DIVERSITY_MASK] & (1 << item)) {
@@ -294,30 +303,22 @@ __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item
 }
 
 // ---- assembler ---------------------------------------------------------------------------------------------
-// Assembler::get_current_protocol (assembler.hpp:353-408).  Returns the protocol record offset or -1.
-__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, CellCodec codec, int H,
-                                          int W, int ar, int ac, int cfg, bool clipped) {
+// Protocol lookup (assembler.hpp:378-408) from the vibes of the surrounding agents (any order; zeros ignored) and
+// their number.  Returns the protocol record offset or -1.
+__device__ inline int mg_select_protocol(const int* dc, int cfg, const uint8_t* near_vibes, int n_agents, bool clipped) {
   uint8_t vibes[8];
-  int nv = 0, n_agents = 0;
-  for (int i = -1; i <= 1; i++)
-    for (int j = -1; j <= 1; j++) {
-      if (i == 0 && j == 0) continue;
-      int rr = ar + i, cc = ac + j;
-      if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
-      uint16_t cv = grid[rr * W + cc];
-      if (codec.is_agent(cv)) {
-        n_agents++;
-        uint8_t v = ag[codec.agent_idx(cv)].vibe;
-        if (v != 0) {  // insertion sort (std::sort of the vibe vector)
-          int p = nv++;
-          while (p > 0 && vibes[p - 1] > v) {
-            vibes[p] = vibes[p - 1];
-            p--;
-          }
-          vibes[p] = v;
-        }
+  int nv = 0;
+  for (int q = 0; q < n_agents && q < 8; q++) {
+    uint8_t v = near_vibes[q];
+    if (v != 0) {  // insertion sort (std::sort of the vibe vector, assembler.hpp:326-331)
+      int p = nv++;
+      while (p > 0 && vibes[p - 1] > v) {
+        vibes[p] = vibes[p - 1];
+        p--;
       }
+      vibes[p] = v;
     }
+  }
   if (clipped) return -1;  // unclip protocols only come from a Clipper (out of scope)
   unsigned long long key = 0;
   for (int i = 0; i < nv; i++) key = (key << 8) | vibes[i];
@@ -338,6 +339,22 @@ __device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, c
   return -1;
 }
 
+// Assembler::get_current_protocol on the grid as it stands (assembler.hpp:353-408).
+__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, CellCodec codec, int H,
+                                          int W, int ar, int ac, int cfg, bool clipped) {
+  uint8_t vibes[8];
+  int n_agents = 0;
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) {
+      if (i == 0 && j == 0) continue;
+      int rr = ar + i, cc = ac + j;
+      if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
+      uint16_t cv = grid[rr * W + cc];
+      if (codec.is_agent(cv)) vibes[n_agents++] = ag[codec.agent_idx(cv)].vibe;
+    }
+  return mg_select_protocol(dc, cfg, vibes, n_agents, clipped);
+}
+
 __device__ inline int mg_kv_lookup(const int* dc, int off, int k) {
   int n = L_n(dc, off);
   for (int i = 0; i < n; i++)
@@ -345,19 +362,20 @@ __device__ inline int mg_kv_lookup(const int* dc, int off, int k) {
   return 0;
 }
 
-// Assembler::onUse (assembler.hpp:455-526)
-__device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
+// Assembler::onUse (assembler.hpp:455-526) given the surrounding agents `near[0..nn)` in the reference's order
+// (NW..SE ring rotated to start at the actor, assembler.hpp:48-92) and their vibes at the time of use.
+__device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx, const int* near, const uint8_t* near_vibes,
+                                             int nn) {
   const int* dc = cx.dc;
   DAsm* as = &cx.as[asm_idx];
   int4 info = cx.asm_info[asm_idx];
-  int ar = info.x, ac = info.y;
   const int* rec = asm_rec(dc, info.z);
   uint32_t max_uses = (uint32_t)rec[AR_MAX_USES];
   if (max_uses > 0 && as->uses_count >= max_uses) return false;
   uint32_t remaining = as->cooldown_end <= cx.step ? 0 : as->cooldown_end - cx.step;
   bool partial = rec[AR_ALLOW_PARTIAL] != 0;
   if (remaining > 0 && !partial) return false;
-  int po = mg_current_protocol(dc, cx.grid, cx.ag, cx.cc, cx.H, cx.W, ar, ac, info.z, as->clipped != 0);
+  int po = mg_select_protocol(dc, info.z, near_vibes, nn, as->clipped != 0);
   if (po < 0) return false;
   // protocol_to_use as (item, amount) lists
   int in_k[MGD_MAX_R], in_v[MGD_MAX_R], out_k[MGD_MAX_R], out_v[MGD_MAX_R];
@@ -399,26 +417,6 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
       out_v[i] = KV_v(dc, oout, i);
     }
   }
-  // surrounding agents, rotated to start at the actor (assembler.hpp:48-92)
-  const DAgent* actor = &cx.ag[ai_actor];
-  int pr[8], pc[8], np = 0, start = -1;
-  for (int i = -1; i <= 1; i++)
-    for (int j = -1; j <= 1; j++) {
-      if (i == 0 && j == 0) continue;
-      int rr = ar + i, cc = ac + j;
-      if (rr < 0 || cc < 0 || rr >= cx.H || cc >= cx.W) continue;
-      if (rr == actor->r && cc == actor->c && start < 0) start = np;
-      pr[np] = rr;
-      pc[np] = cc;
-      np++;
-    }
-  if (start < 0) return false;  // reference throws; cannot happen for a move into the assembler
-  int near[8], nn = 0;
-  for (int q = 0; q < np; q++) {
-    int p = (start + q) % np;
-    uint16_t cv = cx.grid[pr[p] * cx.W + pc[p]];
-    if (cx.cc.is_agent(cv)) near[nn++] = cx.cc.agent_idx(cv);
-  }
   // can_afford_protocol: uint16 totals (assembler.hpp:124-137)
   for (int i = 0; i < n_in; i++) {
     int total = 0;
@@ -434,7 +432,7 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
     int cnt[8];  // remaining required count per distinct position in the vibes list
     for (int i = 0; i < nvib && i < 8; i++) cnt[i] = 1;
     for (int q = 0; q < nn; q++) {
-      uint8_t v = cx.ag[near[q]].vibe;
+      uint8_t v = near_vibes[q];
       if (v == 0) continue;
       int slot = -1;
       for (int i = 0; i < nvib && i < 8; i++)
@@ -481,6 +479,38 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
   return true;
 }
 
+
+// Assembler::onUse on the grid as it stands (general path): gather the surrounding agents, then the core.
+__device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
+  int4 info = cx.asm_info[asm_idx];
+  int ar = info.x, ac = info.y;
+  const DAgent* actor = &cx.ag[ai_actor];
+  int pr[8], pc[8], np = 0, start = -1;
+  for (int i = -1; i <= 1; i++)
+    for (int j = -1; j <= 1; j++) {
+      if (i == 0 && j == 0) continue;
+      int rr = ar + i, cc = ac + j;
+      if (rr < 0 || cc < 0 || rr >= cx.H || cc >= cx.W) continue;
+      if (rr == actor->r && cc == actor->c && start < 0) start = np;
+      pr[np] = rr;
+      pc[np] = cc;
+      np++;
+    }
+  if (start < 0) return false;  // reference throws; cannot happen for a move into the assembler
+  int near[8], nn = 0;
+  uint8_t vibes[8];
+  for (int q = 0; q < np; q++) {
+    int p = (start + q) % np;
+    uint16_t cv = cx.grid[pr[p] * cx.W + pc[p]];
+    if (cx.cc.is_agent(cv)) {
+      near[nn] = cx.cc.agent_idx(cv);
+      vibes[nn] = cx.ag[near[nn]].vibe;
+      nn++;
+    }
+  }
+  return mg_assembler_use_core(cx, ai_actor, asm_idx, near, vibes, nn);
+}
+
 // ---- attack / transfer (attack.hpp:93-253, transfer.hpp:72-150) ----------------------------------------------
 __device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
   const int* dc = cx.dc;
@@ -493,7 +523,6 @@ __device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
   for (int i = 0; i < nc; i++)
     if ((int)actor->amt[KV_k(dc, oc, i)] < (KV_v(dc, oc, i) & 0xFFFF)) return false;
   int ag = group_rec(dc, actor->group)[GR_NAME_IDX], tg = group_rec(dc, target->group)[GR_NAME_IDX];
-  int* sda = cx.sd + ai * cx.SA;
   bool blocked = false;
   if (dc[DC_HAS_DEFENSE]) {
     int weapon = 0, armor = 0;
@@ -521,7 +550,7 @@ __device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
     if (can) {
       // _consume_defense_resources recomputes the powers before consuming; nothing changed in between.
       for (int i = 0; i < nd; i++) inv_update(cx, ti, KV_k(dc, od, i), -((KV_v(dc, od, i) & 0xFFFF) + bonus));
-      sda[cx.AS.attack_blocked_by(tg)] += 1;
+      mg_stat_add(cx, ai, cx.AS.attack_blocked_by(tg), 1);
       blocked = true;
     }
   }
@@ -541,10 +570,10 @@ __device__ inline bool mg_try_attack(Ctx& cx, int ai, uint16_t target_cell) {
       }
     }
     if (ag == tg) {
-      sda[cx.AS.attack_friendly_fire()] += 1;
+      mg_stat_add(cx, ai, cx.AS.attack_friendly_fire(), 1);
     } else {
-      sda[cx.AS.attack_hit(tg)] += 1;
-      cx.sd[ti * cx.SA + cx.AS.attack_hit_by(ag)] += 1;
+      mg_stat_add(cx, ai, cx.AS.attack_hit(tg), 1);
+      mg_stat_add(cx, ti, cx.AS.attack_hit_by(ag), 1);
     }
   }
   for (int i = 0; i < nc; i++)
@@ -588,22 +617,21 @@ __device__ inline bool mg_try_transfer(Ctx& cx, int ai, uint16_t target_cell) {
     int d = KV_v(dc, ot, i);
     if (d > 0 && d > mg_free_space(cx, target, KV_k(dc, ot, i))) return false;
   }
-  int* sda = cx.sd + ai * cx.SA;
   for (int i = 0; i < na; i++) {
     int d = KV_v(dc, oa, i), item = KV_k(dc, oa, i);
     if (d != 0) {
       int actual = inv_update(cx, ai, item, d);
-      if (actual != 0) sda[cx.AS.transfer_self(item)] += actual;
+      if (actual != 0) mg_stat_add(cx, ai, cx.AS.transfer_self(item), actual);
     }
   }
   for (int i = 0; i < nt; i++) {
     int d = KV_v(dc, ot, i), item = KV_k(dc, ot, i);
     if (d != 0) {
       int actual = inv_update(cx, ti, item, d);
-      if (actual != 0) sda[cx.AS.transfer_to(tg, item)] += actual;
+      if (actual != 0) mg_stat_add(cx, ai, cx.AS.transfer_to(tg, item), actual);
     }
   }
-  sda[cx.AS.transfer_count()] += 1;
+  mg_stat_add(cx, ai, cx.AS.transfer_count(), 1);
   return true;
 }
 
@@ -639,7 +667,7 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
       ta->c = actor->c;
       actor->r = (uint16_t)tr;
       actor->c = (uint16_t)tc;
-      cx.sd[ai * cx.SA + cx.AS.swap()] += 1;
+      mg_stat_add(cx, ai, cx.AS.swap(), 1);
       return true;
     }
     return false;  // Agent::onUse (agent.cpp:179-185)
@@ -651,11 +679,10 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
 // ActionHandler::handle_action (action_handler.hpp:99-153)
 __device__ inline bool mg_handle_action(Ctx& cx, int ai, int kind, int arg) {
   DAgent* actor = &cx.ag[ai];
-  int* sda = cx.sd + ai * cx.SA;
   const int* dc = cx.dc;
   if (actor->frozen != 0) {
-    sda[cx.AS.frozen_ticks()] += 1;
-    sda[cx.AS.frozen_ticks_group()] += 1;
+    mg_stat_add(cx, ai, cx.AS.frozen_ticks(), 1);
+    mg_stat_add(cx, ai, cx.AS.frozen_ticks_group(), 1);
     if (actor->frozen > 0) actor->frozen -= 1;
     return false;
   }
