@@ -115,6 +115,10 @@ int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream);
 int mg_set_profiling(mg_handle* h, int enabled);
 int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps);
 
+/* Diagnostic (no reference counterpart): enable / read per-environment cycle stamps u64[E][16] of the observation
+ * kernel's phases. */
+int mg_debug_stamps(mg_handle* h, unsigned long long* out, int enable);
+
 int mg_destroy(mg_handle* h);
 
 #ifdef __cplusplus

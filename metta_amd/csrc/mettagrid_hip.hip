@@ -27,6 +27,10 @@
 
 #define MG_THREADS 256
 #define MG_WIN_MARGIN 32
+#define MG_STAMP(slot)                                                     \
+  do {                                                                    \
+    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); \
+  } while (0)
 #define MG_DC_LDS_MAX_WORDS 6144  // 24 KiB
 
 struct KArgs {
@@ -38,7 +42,9 @@ struct KArgs {
   const int* map_nasm;        // [P]
   const float* map_objcount;  // [P][n_cells]
   int P, H, W, HW, NAmax, n_cells;
-  int NW, TS, NOBJ;  // wall types, token-list stride (tokens per object), objects per env (NW + A + NAmax)
+  int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
+  int CB;                  // bits needed for the largest per-object token count
+  int TSW, TSA, TSS, HEAP; // token-list strides of walls / agents / assemblers; heap size in tokens
   DEnv* env;
   uint32_t* mt;  // [E][624]
   DAgent* agents;
@@ -74,6 +80,8 @@ struct KArgs {
   const float* t_gstats;      // [P][SG]
   const uint32_t* t_gtouched; // [P][GW]
   uint32_t* mt_init;          // [E][624] std::mt19937(seed) state of each env's seed
+  int diag;                   // diagnostic ablation bits (MG_DIAG env var): 1 = no obs stores, 2 = no scatter, 4 = no lookups
+  unsigned long long* dbg;    // optional [E][16] cycle stamps (diagnostic builds of the phases; null = off)
   int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
   int auto_reset, map_stride;
   const int* reset_envs;  // reset kernel only
@@ -97,15 +105,16 @@ struct Lds {
   float* tokacc;  // [3] tokens_written / dropped / free_space accumulators
   int* flags;     // [4]
   uint8_t* rows;
-  uint8_t* ocnt;    // [NOBJ] tokens of each object this step
-  uint16_t* heap;   // [NOBJ][TS] (feature | value << 8)
+  uint32_t* ocnt;   // [NOBJ] per object this step: heap offset | token count << 16
+  uint16_t* heap;   // token lists (feature | value << 8): [NW][TSW] walls, [A][TSA] agents, [NA][TSS] assemblers
+  int4* ainfo;      // [NA] static assembler info of the map (r, c, cfg, object id)
   uint32_t* pat;    // [P] (dr+8) | (dc+8) << 8 | location byte << 16
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
-                                           int ROWB, int nwaves, int dcw, int NOBJ, int TS, int NP) {
+                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -118,9 +127,11 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
-  size_t oc = take(nwaves ? (size_t)NOBJ : 0), hp = take(nwaves ? (size_t)NOBJ * TS * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
+  size_t oc = take(nwaves ? (size_t)NOBJ * 4 : 0), hp = take(nwaves ? (size_t)HEAP * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
+  size_t ai = take(nwaves ? (size_t)(NA > 0 ? NA : 1) * 16 : 0);
   if (l) {
-    l->ocnt = (uint8_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
@@ -132,7 +143,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
 
 // LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
 __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
-                                               int dcw, int NOBJ, int TS, int NP) {
+                                               int dcw, int NOBJ, int HEAP, int NP) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -143,9 +154,11 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   if (l) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
-  size_t oc = take((size_t)NOBJ), hp = take((size_t)NOBJ * TS * 2), pt = take((size_t)NP * 4);
+  size_t oc = take((size_t)NOBJ * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
+  size_t ai = take((size_t)(NA > 0 ? NA : 1) * 16);
   if (l) {
-    l->ocnt = (uint8_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
     l->rows = (uint8_t*)(base + rows);
@@ -173,17 +186,25 @@ __device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, 
   for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = cc.agent(i);
 }
 
+__device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
+  return obj < a.NW ? obj * a.TSW
+                    : (obj < a.NW + a.A ? a.NW * a.TSW + (obj - a.NW) * a.TSA
+                                        : a.NW * a.TSW + a.A * a.TSA + (obj - a.NW - a.A) * a.TSS);
+}
+
 // Build every object's token list once (they are observer independent) and the pattern table.
+// Requires l.ainfo (the map's static assembler info) staged + a barrier before.
 __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
   const int* dc = a.dc;
   const CellCodec cc{a.NW, a.A};
-  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  const int4* asm_info = l.ainfo;
   const int nasm = a.map_nasm[map_id];
   for (int obj = tid; obj < a.NOBJ; obj += nt) {
-    PairOut out{l.heap + (size_t)obj * a.TS, 0};
+    const int ho = mg_heap_off(a, obj);
+    PairOut out{l.heap + ho, 0};
     if (obj < a.NW + a.A + nasm)
       mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out);
-    l.ocnt[obj] = (uint8_t)out.n;
+    l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
   }
   const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
   for (int p = tid; p < P; p += nt) {
@@ -246,8 +267,9 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t ste
       if (r >= r_start && r < r_end && c >= c_start && c < c_end) {
         uint16_t cv = l.grid[r * W + c];
         if (cv != 0) {
-          obj = (int)cv - 1;
-          cnt = l.ocnt[obj];
+          uint32_t meta = l.ocnt[(int)cv - 1];
+          obj = (int)(meta & 0xFFFF);  // heap offset of the object's token list
+          cnt = (int)(meta >> 16);
         }
       }
     }
@@ -265,7 +287,7 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t ste
     }
     off += base;
     if (cnt > 0 && off < T) {
-      const uint16_t* src = l.heap + (size_t)obj * a.TS;
+      const uint16_t* src = l.heap + obj;
       uint8_t loc = (uint8_t)(pk >> 16);
       int n = min(cnt, T - off);
       uint8_t* dst = row + off * 3;
@@ -1139,15 +1161,16 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 // whole agents' token rows in LDS and streams them to HBM (bindings/mettagrid_c.cpp:652-677).
 // ------------------------------------------------------------------------------------------------------------
 template <bool DCL>
-__global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
+__global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
   Lds l;
-  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0, a.NOBJ, a.TS, a.dc[DC_PATTERN_N]);
+  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
   if (DCL) {
     for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
     a.dc = l.dc;
   }
+  MG_STAMP(0);
   DEnv env = a.env[e];
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   {
@@ -1158,15 +1181,21 @@ __global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
     uint4* d2 = (uint4*)l.as;
     for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
     for (int i = tid; i < a.A; i += nt) l.exec[i] = a.exec[(size_t)e * a.A + i];
+    const int4* ai_src = a.map_asm + (size_t)env.map_id * a.NAmax;
+    for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = ai_src[i];
     if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
   }
   __syncthreads();
+  MG_STAMP(1);
   mg_overlay_agents(a, l, tid, nt);
   __syncthreads();
+  MG_STAMP(2);
   mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);
   __syncthreads();
+  MG_STAMP(3);
   mg_encode_all(a, l, e, env.step, l.exec, true, tid, nt);
   __syncthreads();
+  MG_STAMP(4);
   if (tid == 0) {
     mg_token_stats(a, l, 1);
     float* gs_ = a.gstats + (size_t)e * a.SG;
@@ -1175,7 +1204,9 @@ __global__ __launch_bounds__(MG_THREADS) void mg_obs_kernel(KArgs a) {
     gs_[2] = l.tokacc[2];
   }
   __syncthreads();
+  MG_STAMP(5);
   mg_rewards_and_flags(a, l, e, env, tid, nt);
+  MG_STAMP(6);
 }
 
 // Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.
@@ -1184,7 +1215,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.TS, a.dc[DC_PATTERN_N]);
+  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
   DEnv env = a.env[e];
   env.seed = a.reset_seeds[blockIdx.x];
   env.map_id = (uint32_t)a.reset_maps[blockIdx.x];
@@ -1197,6 +1228,10 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
   mg_overlay_agents(a, l, tid, nt);
+  {
+    const int4* ai_src = a.map_asm + (size_t)env.map_id * a.NAmax;
+    for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = ai_src[i];
+  }
   __syncthreads();
   mg_build_tokens(a, l, (int)env.map_id, 0, tid, nt);
   __syncthreads();
@@ -1373,6 +1408,8 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
     bool ok = c.A <= 64 && c.regen_interval == 0;
     for (int v : c.vibe_handler) ok = ok && v == 0;
     for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
+    const char* dg = getenv("MG_DIAG");
+    k.diag = dg ? atoi(dg) : 0;
     const char* force = getenv("MG_FORCE_GENERAL");
     if (force && force[0] == '1') ok = false;
     k.fast = ok ? 1 : 0;
@@ -1485,20 +1522,27 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   }
   h->host_asm = asm_lists;
   // LDS budget
-  // token-list stride: the most tokens any object can show (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578)
-  int TS = 1;
-  for (const auto& wl : c.walls) TS = std::max(TS, (int)wl.tags.size() + 1);
-  for (const auto& g : c.groups) TS = std::max(TS, 3 + c.R * c.n_inv_tokens + (int)g.tags.size());
+  // token-list strides: the most tokens an object of each kind can show (wall.hpp:26-38, agent.cpp:187-213,
+  // assembler.hpp:528-578)
+  int TSW = 1, TSA = 1, TSS = 1;
+  for (const auto& wl : c.walls) TSW = std::max(TSW, (int)wl.tags.size() + 1);
+  for (const auto& g : c.groups) TSA = std::max(TSA, 3 + c.R * c.n_inv_tokens + (int)g.tags.size());
   for (const auto& a : c.assemblers) {
     int io = 0;
     for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
-    TS = std::max(TS, 3 + io + (int)a.tags.size() + 1);
+    TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
   }
-  if (TS > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
+  if (TSW > 255 || TSA > 255 || TSS > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
   const int NOBJ = (int)c.walls.size() + c.A + NAmax;
+  const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS;
   const int NP = c.obs_h * c.obs_w;
-  k.NW = (int)c.walls.size(); k.TS = TS; k.NOBJ = NOBJ;
-  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, TS, NP);
+  k.NW = (int)c.walls.size(); k.NOBJ = NOBJ; k.TSW = TSW; k.TSA = TSA; k.TSS = TSS; k.HEAP = HEAP;
+  {
+    int mx = std::max(TSW, std::max(TSA, TSS));
+    k.CB = 1;
+    while ((1 << k.CB) <= mx) k.CB++;
+  }
+  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
   if (lds > 160 * 1024)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   for (void* p : h->map_allocs) (void)hipFree(p);
@@ -1522,11 +1566,11 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
   h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw, NOBJ, TS, NP);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw, NOBJ, HEAP, NP);
   if (h->lds_act > 160 * 1024 || h->lds_obs > 160 * 1024) {
     h->dc_lds = false;
     h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
-    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, TS, NP);
+    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
   }
   if (h->dc_lds) {
     HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
@@ -1868,6 +1912,18 @@ int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps) {
   }
   *n_steps = n;
   h->ev_count = 0;
+  return 0;
+}
+
+// Diagnostic: per-environment cycle stamps of the observation kernel's phases (s_memtime, 100 MHz units on gfx950).
+int mg_debug_stamps(mg_handle* h, unsigned long long* out, int enable) {
+  if (!h) return fail("mg_debug_stamps: NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (enable && !h->k.dbg) {
+    if (dalloc(h, &h->k.dbg, (size_t)h->E * 16)) return 1;
+  }
+  if (out && h->k.dbg) HIPCHK(hipMemcpy(out, h->k.dbg, (size_t)h->E * 16 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -32,7 +32,7 @@ enum MgGr {
 enum MgWr { WR_TYPE_ID = 0, WR_VIBE, WR_OFF_TAGS, WR_WORDS };
 enum MgAr {
   AR_TYPE_ID = 0, AR_VIBE, AR_ALLOW_PARTIAL, AR_MAX_USES, AR_CLIP_IMMUNE, AR_START_CLIPPED, AR_CHEST_DIST, AR_OFF_TAGS,
-  AR_N_PROTOCOLS, AR_OFF_PTABLE, AR_N_KEYS, AR_OFF_KEYS, AR_WORDS
+  AR_N_PROTOCOLS, AR_OFF_PTABLE, AR_N_KEYS, AR_OFF_KEYS, AR_SIMPLE_PO, AR_WORDS
 };
 enum MgPr { PR_MIN_AGENTS = 0, PR_COOLDOWN, PR_OFF_VIBES, PR_OFF_IN, PR_OFF_OUT, PR_OFF_IN_S, PR_OFF_OUT_S, PR_WORDS };
 
@@ -234,6 +234,12 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
         kt.push_back(b.put_list(k.protocols));
       }
       { int o = b.reserve((int)kt.size()); for (size_t i = 0; i < kt.size(); i++) b.w[(size_t)o + i] = kt[i]; rec[AR_OFF_KEYS] = o; }
+      // When the only key is 0 and its first (largest min_agents) protocol needs no agents, get_current_protocol
+      // (assembler.hpp:378-408) returns that protocol whatever surrounds the assembler: skip the neighbour scan.
+      rec[AR_SIMPLE_PO] = -1;
+      if (a.keys.size() == 1 && a.keys[0].key == 0 && !a.keys[0].protocols.empty() &&
+          a.protocols[(size_t)a.keys[0].protocols[0]].min_agents == 0)
+        rec[AR_SIMPLE_PO] = pt[(size_t)a.keys[0].protocols[0]];
       int o = b.reserve(AR_WORDS);
       for (int i = 0; i < AR_WORDS; i++) b.w[(size_t)o + (size_t)i] = rec[i];
       table.push_back(o);

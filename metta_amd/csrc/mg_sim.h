@@ -857,7 +857,9 @@ __device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, con
       out.put(dc[DC_FID0 + MG_F_REMAINING_USES], (int)ru);
     }
     if (dc[DC_PROTO_OBS]) {
-      int po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, s->clipped != 0);
+      int po = rec[AR_SIMPLE_PO];
+      if (s->clipped) po = -1;
+      else if (po < 0) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, false);
       if (po >= 0) {
         int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
         for (int i = 0; i < ni; i++)

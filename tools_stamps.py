@@ -1,0 +1,20 @@
+import sys, json, ctypes as ct
+sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from metta_amd.batch import MettaGridBatch
+from metta_amd.builder import make_arena
+from metta_amd import native
+z=np.load('/root/repo/tests/golden/arena24_map_pool.npz'); meta=json.loads(bytes(z['meta']).decode()); names=np.array(meta['cell_names']); pool=[names[m] for m in z['maps']]
+E=4096
+b=MettaGridBatch(make_arena(24),E,pool,seeds=list(range(E)),map_ids=[e%64 for e in range(E)])
+tab=torch.randint(0,5,(64,E*24),device='cuda',dtype=torch.int32)
+for t in range(50): b.step(tab[t%64])
+torch.cuda.synchronize()
+native.check(b.L.mg_debug_stamps(b._h, None, 1))
+b.step(tab[0]); torch.cuda.synchronize()
+out=np.zeros((E,16),np.uint64)
+native.check(b.L.mg_debug_stamps(b._h, out.ctypes.data_as(ct.POINTER(ct.c_uint64)), 1))
+d=np.diff(out[:,:7].astype(np.int64),axis=1)
+print("phase medians (stamp units):", np.median(d,axis=0), "mean", d.mean(axis=0))
+print("total per block median", np.median(out[:,6].astype(np.int64)-out[:,0].astype(np.int64)))
+print("kernel span", int(out[:,6].max()-out[:,0].min()))
