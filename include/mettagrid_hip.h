@@ -100,6 +100,15 @@ int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream);
 int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, uint32_t* seed, uint32_t* episodes,
                 void* stream);
 
+/* All environments' bookkeeping words in one copy: u32 out[E][8] = {current_step, rng index, seed, map_id,
+ * episodes finished, pending early-reset step, done flag, error flag}.  (Reference: `current_step`, `_seed`; the
+ * episode counter lets a host poll for finished episodes every k steps instead of every step.) */
+int mg_env_table(mg_handle* h, uint32_t* out, void* stream);
+
+/* Per-agent episode rewards f32[A] and length of the most recently FINISHED episode of `env`
+ * (reference: `get_episode_rewards`, mettagrid_c.cpp:928-930, read by StatsTracker.on_episode_end). */
+int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, void* stream);
+
 /* `MettaGrid::set_inventory` (mettagrid_c.cpp:959-965; Agent::set_inventory, agent.cpp:54-72): items/amounts in
  * the iteration order of the converted map (the host language orders them, metta_amd/umap.py). */
 int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* items, const int32_t* amounts, void* stream);

@@ -171,6 +171,18 @@ class MettaGridBatch:
         )
         return {"current_step": step.value, "map_id": mid.value, "seed": seed.value, "episodes": eps.value}
 
+    def env_table(self) -> np.ndarray:
+        """u32 [E, 8]: current_step, rng index, seed, map_id, episodes, early_reset, done, error."""
+        out = np.zeros((self.num_envs, 8), np.uint32)
+        native.check(self.L.mg_env_table(self._h, _p(out, ct.c_uint32), self._stream()))
+        return out
+
+    def finished_rewards(self, env: int):
+        r = np.zeros(self.num_agents, np.float32)
+        steps = ct.c_uint32()
+        native.check(self.L.mg_finished_rewards(self._h, env, _p(r, ct.c_float), ct.byref(steps), self._stream()))
+        return r, int(steps.value)
+
     def current_step(self, env: int) -> int:
         return self.env_info(env)["current_step"]
 

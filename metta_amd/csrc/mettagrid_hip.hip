@@ -1915,6 +1915,25 @@ int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps) {
   return 0;
 }
 
+int mg_env_table(mg_handle* h, uint32_t* out, void* stream) {
+  if (!h || !out) return fail("mg_env_table: NULL argument");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  static_assert(sizeof(DEnv) == 32, "DEnv is 8 words");
+  HIPCHK(hipMemcpy(out, h->k.env, (size_t)h->E * sizeof(DEnv), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, void* stream) {
+  if (!h || !rewards) return fail("mg_finished_rewards: NULL argument");
+  if (env < 0 || env >= h->E) return fail("mg_finished_rewards: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(rewards, h->k.fin_ep_rewards + (size_t)env * h->k.A, (size_t)h->k.A * 4, hipMemcpyDeviceToHost));
+  if (steps) HIPCHK(hipMemcpy(steps, h->k.fin_steps + env, 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // Diagnostic: per-environment cycle stamps of the observation kernel's phases (s_memtime, 100 MHz units on gfx950).
 int mg_debug_stamps(mg_handle* h, unsigned long long* out, int enable) {
   if (!h) return fail("mg_debug_stamps: NULL handle");

@@ -1,0 +1,53 @@
+"""Multi-GPU: environments shard across ranks as independent instances; the only collective is the all-reduce of
+the finished-episode summary vector (pattern of `metta/rl/advantage.py:127-145`).
+
+One process per GPU, `torch.distributed` with backend "nccl" (= RCCL over xGMI on ROCm) for device tensors or
+"gloo" for the CPU rehearsal used by the tests.  The vector is < 1 KB, so the all-reduce is latency bound.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(num_envs_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Env index range [lo, hi) of `rank`: contiguous blocks, remainders to the low ranks."""
+    base, rem = divmod(num_envs_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_seeds(base_seed: int, num_envs_total: int, rank: int, world: int) -> np.ndarray:
+    """pufferlib convention env i -> seed base + i (PUF/vector.py:90), restricted to this rank's shard."""
+    lo, hi = shard_range(num_envs_total, rank, world)
+    return ((np.arange(lo, hi, dtype=np.int64) + base_seed) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def all_reduce_summary(summary: np.ndarray, device=None) -> np.ndarray:
+    """Sum the per-rank summary vector [episodes, sum(len), sum(reward), game stat sums...] over all ranks."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return np.asarray(summary, dtype=np.float64)
+    t = torch.as_tensor(np.asarray(summary, dtype=np.float64))
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def summary_to_metrics(summary: np.ndarray, game_slot_names: list[str], agents_per_env: int) -> dict:
+    """Means per finished episode, keyed like the reference's rollout stats (`metta/rl/stats.py:18-49`)."""
+    n = float(summary[0])
+    if n <= 0:
+        return {"episodes": 0.0}
+    out = {
+        "episodes": n,
+        "episode_length": float(summary[1]) / n,
+        "episode_reward_per_agent": float(summary[2]) / (n * agents_per_env),
+    }
+    for i, name in enumerate(game_slot_names):
+        if summary[3 + i] != 0:
+            out[f"game/{name}"] = float(summary[3 + i]) / n
+    return out

@@ -57,6 +57,8 @@ SYMBOLS = {
     "mg_num_assemblers": (ct.c_int, [_vp, ct.c_int]),
     "mg_assembler_state": (ct.c_int, [_vp, ct.c_int, _i32p, _vp]),
     "mg_env_info": (ct.c_int, [_vp, ct.c_int, _u32p, _i32p, _u32p, _u32p, _vp]),
+    "mg_env_table": (ct.c_int, [_vp, _u32p, _vp]),
+    "mg_finished_rewards": (ct.c_int, [_vp, ct.c_int, _f32p, _u32p, _vp]),
     "mg_set_inventory": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _vp]),
     "mg_finished_summary": (ct.c_int, [_vp, _f64p, ct.c_int, _vp]),
     "mg_set_profiling": (ct.c_int, [_vp, ct.c_int]),

@@ -1,0 +1,324 @@
+"""Device-resident vectorised environment with the reference's PufferEnv / pufferlib-vecenv protocol.
+
+Drop-in seam:
+
+* `MettaGridDeviceVecEnv` speaks `pufferlib.vector.Serial/Multiprocessing`'s protocol
+  (`PUF/vector.py:56-182,254-546`): `async_reset(seed)`, `recv() -> (obs, rew, term, trunc, teacher_actions, infos,
+  agent_ids, masks)`, `send(actions)`, `reset/step`, `close`, and the attributes `num_agents`,
+  `agents_per_batch`, `num_envs`, `single_observation_space`, `single_action_space`, `observation_space`,
+  `action_space`, `driver_env`, `emulated`.  Env i gets seed `seed + i` (`PUF/vector.py:90,382`).
+  Everything it returns is a torch ROCm tensor aliasing the library's HBM buffers -- there are no worker
+  processes, no shared-memory segments and no semaphores to poll.
+* per-env behaviour is `MettaGridPufferEnv`'s (`PY/envs/mettagrid_puffer_env.py:148-183`): auto-reset at the
+  start of the step after an episode ended; `infos` carries the `StatsTracker` dictionaries of the episodes that
+  just finished (`PY/envs/stats_tracker.py:26-107`: game stats, agent stats averaged over agents, attributes);
+  the first episode of every env is cut at a uniform random step (`EarlyResetHandler`,
+  `PY/envs/early_reset_handler.py:6-20`).
+* `DeviceTrainingEnvironment` implements the `TrainingEnvironment` ABC of `metta/rl/training/
+  training_environment.py:85-118` (`get_observations`, `send_actions`, `batch_info`, spaces, `policy_env_info`);
+  `send_actions` takes a device tensor (the line that changes in `CoreTrainingLoop.rollout_phase`,
+  `metta/rl/training/core.py:180`, is `env.send_actions(td["actions"])` without `.cpu().numpy()`).
+"""
+
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Any, Optional, Sequence
+
+import numpy as np
+
+from metta_amd.batch import MettaGridBatch
+from metta_amd.compile import compile_game
+from metta_amd.config import MettaGridConfig
+from metta_amd.spaces import Box, Discrete, joint_space
+
+RESET, SEND, RECV = 0, 2, 3
+
+
+class APIUsageError(RuntimeError):
+    """pufferlib.APIUsageError (PUF/pufferlib.py:361-366)."""
+
+
+@dataclass
+class PolicyEnvInterface:
+    """What a policy needs to know about the environment (PY/policy/policy_env_interface.py:66-117)."""
+
+    obs_features: list
+    tags: list[str]
+    action_names: list[str]
+    num_agents: int
+    observation_space: Any
+    action_space: Any
+    obs_width: int
+    obs_height: int
+    assembler_protocols: list = field(default_factory=list)
+    tag_id_to_name: dict = field(default_factory=dict)
+
+    @staticmethod
+    def from_mg_cfg(cfg: MettaGridConfig) -> "PolicyEnvInterface":
+        game = cfg.game
+        id_map = game.id_map()
+        tags = id_map.tag_names()
+        asm = game.objects.get("assembler")
+        return PolicyEnvInterface(
+            obs_features=id_map.features(),
+            tags=tags,
+            action_names=[a.name for a in game.actions.actions()],
+            num_agents=game.num_agents,
+            observation_space=Box(0, 255, (game.obs.num_tokens, game.obs.token_dim), dtype=np.uint8),
+            action_space=Discrete(len(game.actions.actions())),
+            obs_width=game.obs.width,
+            obs_height=game.obs.height,
+            assembler_protocols=list(getattr(asm, "protocols", []) or []),
+            tag_id_to_name={i: t for i, t in enumerate(tags)},
+        )
+
+
+class MettaGridDeviceVecEnv:
+    """E MettaGrid environments on one GPU behind the pufferlib vecenv protocol."""
+
+    def __init__(
+        self,
+        cfg: MettaGridConfig,
+        num_envs: int,
+        maps: Optional[Sequence] = None,
+        num_maps: int = 64,
+        device: int = 0,
+        seed: int = 0,
+        early_reset: bool = True,
+        map_seed: int = 0,
+    ):
+        self.cfg = cfg
+        self.policy_env_info = PolicyEnvInterface.from_mg_cfg(cfg)
+        game = cfg.game
+        if maps is None:
+            rng = np.random.default_rng(map_seed)
+            maps = [game.map_builder.build(rng) for _ in range(num_maps)]
+        self.compiled = compile_game(cfg, init_obs_passes=2)  # the Puffer path: ctor + set_buffers
+        self.batch = MettaGridBatch(cfg, num_envs, maps, device=device, compiled=self.compiled)
+        self.batch.set_auto_reset(True, 1)
+        self.num_environments = int(num_envs)
+        self.agents_per_env = game.num_agents
+        self.num_agents = self.num_environments * self.agents_per_env
+        self.agents_per_batch = self.num_agents
+        self.single_observation_space = self.policy_env_info.observation_space
+        self.single_action_space = self.policy_env_info.action_space
+        self.observation_space = joint_space(self.single_observation_space, self.agents_per_batch)
+        self.action_space = joint_space(self.single_action_space, self.agents_per_batch)
+        self.emulated = False
+        self.driver_env = self
+        self._early_reset = early_reset
+        self._seed = seed
+        self._label = cfg.label
+        torch = self.batch._torch
+        self.agent_ids = torch.arange(self.num_agents, device=self.batch.device)
+        self.teacher_actions = torch.zeros(self.num_agents, dtype=torch.int32, device=self.batch.device)
+        self.infos: list[dict] = []
+        self.flag = RESET
+        self._episodes_seen = np.zeros(self.num_environments, dtype=np.int64)
+        self._per_label_rewards: dict[str, float] = {}
+        self._done_prev = None
+        self.stats_every = 1  # poll finished episodes every k steps (1 = like the reference; larger = fewer syncs)
+        self._steps = 0
+
+    # ---- buffers (pufferlib.set_buffers names, PUF/pufferlib.py:18-45) ------------------------------------
+    @property
+    def num_envs(self) -> int:
+        return self.agents_per_batch  # pufferlib's Serial/Multiprocessing report agents here (vector.py:60-62)
+
+    @property
+    def observations(self):
+        return self.batch.observations
+
+    @property
+    def rewards(self):
+        return self.batch.rewards
+
+    @property
+    def terminals(self):
+        return self.batch.terminals
+
+    @property
+    def truncations(self):
+        return self.batch.truncations
+
+    @property
+    def masks(self):
+        return self.batch.masks
+
+    @property
+    def actions(self):
+        return self.batch.actions
+
+    # ---- protocol ------------------------------------------------------------------------------------------
+    def async_reset(self, seed: Optional[int] = None) -> None:
+        if seed is not None:
+            self._seed = int(seed)
+        E = self.num_environments
+        seeds = (np.arange(E, dtype=np.int64) + self._seed) & 0xFFFFFFFF
+        self.batch.reset(seeds=seeds.astype(np.uint32))
+        if self._early_reset and self.cfg.game.max_steps > 0:
+            # EarlyResetHandler: numpy's global RNG, uniform in [1, max_steps] (early_reset_handler.py:15)
+            self.batch.set_early_reset(np.random.randint(1, self.cfg.game.max_steps + 1, size=E).astype(np.uint32))
+        else:
+            self.batch.set_early_reset(None)
+        self._episodes_seen[:] = 0
+        self.infos = []
+        self._done_prev = None
+        self.flag = RECV
+
+    def recv(self):
+        if self.flag != RECV:
+            raise APIUsageError("Call reset before stepping")
+        self.flag = SEND
+        b = self.batch
+        infos, self.infos = self.infos, []
+        return (b.observations, b.rewards, b.terminals, b.truncations, self.teacher_actions, infos, self.agent_ids, b.masks)
+
+    def send(self, actions) -> None:
+        if self.flag != SEND:
+            raise APIUsageError("Call (async) reset + recv before sending")
+        self.flag = RECV
+        b = self.batch
+        torch = b._torch
+        if not isinstance(actions, torch.Tensor):
+            a = np.asarray(actions)
+            if a.size != self.num_agents:
+                raise APIUsageError("Actions do not match action space")
+            actions = torch.as_tensor(a.reshape(-1)).to(dtype=torch.int32)
+        b.step(actions.reshape(-1))
+        self._steps += 1
+        if self.stats_every == 1:
+            self._collect_infos()  # episodes that ended on this step: same recv() as the reference delivers them
+        elif self._steps % self.stats_every == 0:
+            self._collect_finished()  # poll the episode counters; infos arrive up to stats_every steps late
+
+    def reset(self, seed: int = 42):
+        self.async_reset(seed)
+        obs, _, _, _, _, infos, _, _ = self.recv()
+        return obs, infos
+
+    def step(self, actions):
+        self.send(actions)
+        obs, rew, term, trunc, _, infos, _, _ = self.recv()
+        return obs, rew, term, trunc, infos
+
+    def notify(self) -> None:
+        pass
+
+    def close(self) -> None:
+        self.batch.close()
+
+    # ---- StatsTracker.on_episode_end (PY/envs/stats_tracker.py:26-107) ---------------------------------------
+    def _collect_infos(self) -> None:
+        b = self.batch
+        E, A = self.num_environments, self.agents_per_env
+        done = (b.terminals.view(E, A).all(dim=1) | b.truncations.view(E, A).all(dim=1)).nonzero().flatten().tolist()
+        for e in done:
+            stats = b.get_episode_stats(e, last_finished=False)
+            ep_rewards = b.episode_rewards.view(E, A)[e].cpu().numpy()
+            info = b.env_info(e)
+            agent: dict[str, float] = {}
+            for st in stats["agent"]:
+                for k, v in st.items():
+                    agent[k] = agent.get(k, 0) + v
+            agent = {k: v / A for k, v in agent.items()}
+            mean_reward = float(ep_rewards.mean())
+            self._per_label_rewards[self._label] = mean_reward
+            self.infos.append(
+                {
+                    "game": stats["game"],
+                    "agent": agent,
+                    "per_label_rewards": dict(self._per_label_rewards),
+                    "attributes": {
+                        "seed": info["seed"],
+                        "map_w": b.map_width,
+                        "map_h": b.map_height,
+                        "steps": info["current_step"],
+                        "max_steps": self.cfg.game.max_steps,
+                        "completion_time": time.time(),
+                    },
+                }
+            )
+
+
+    def _collect_finished(self) -> None:
+        """Low-sync variant: episodes whose counter advanced since the last poll, from the snapshot the act kernel
+        takes when it restarts an environment (only the latest finished episode of an env is kept)."""
+        b = self.batch
+        table = b.env_table()
+        A = self.agents_per_env
+        for e in np.nonzero(table[:, 4] > self._episodes_seen)[0].tolist():
+            self._episodes_seen[e] = int(table[e, 4])
+            stats = b.get_episode_stats(e, last_finished=True)
+            ep_rewards, steps = b.finished_rewards(e)
+            agent: dict[str, float] = {}
+            for st in stats["agent"]:
+                for k, v in st.items():
+                    agent[k] = agent.get(k, 0) + v
+            self._per_label_rewards[self._label] = float(ep_rewards.mean())
+            self.infos.append(
+                {
+                    "game": stats["game"],
+                    "agent": {k: v / A for k, v in agent.items()},
+                    "per_label_rewards": dict(self._per_label_rewards),
+                    "attributes": {
+                        "seed": int(table[e, 2]), "map_w": b.map_width, "map_h": b.map_height, "steps": steps,
+                        "max_steps": self.cfg.game.max_steps, "completion_time": time.time(),
+                    },
+                }
+            )
+
+
+@dataclass
+class BatchInfo:
+    target_batch_size: int
+    batch_size: int
+    num_envs: int
+
+
+class DeviceTrainingEnvironment:
+    """`TrainingEnvironment` (metta/rl/training/training_environment.py:85-118) over the device vecenv."""
+
+    def __init__(self, cfg: MettaGridConfig, num_envs: int, device: int = 0, seed: int = 0, **vec_kwargs):
+        self._vecenv = MettaGridDeviceVecEnv(cfg, num_envs, device=device, seed=seed, **vec_kwargs)
+        self._vecenv.async_reset(seed)
+        self._num_envs = num_envs
+
+    def close(self) -> None:
+        self._vecenv.close()
+
+    def get_observations(self):
+        o, r, d, t, ta, info, env_id, mask = self._vecenv.recv()
+        training_env_id = slice(0, self._vecenv.num_agents)
+        num_steps = self._vecenv.num_agents  # masks are all ones (BIND/mettagrid_c.cpp:983-995)
+        return o, r, d, t, ta, info, training_env_id, mask, num_steps
+
+    def send_actions(self, actions) -> None:
+        self._vecenv.send(actions)
+
+    @property
+    def batch_info(self) -> BatchInfo:
+        n = self._vecenv.num_agents
+        return BatchInfo(target_batch_size=n, batch_size=self._num_envs, num_envs=self._num_envs)
+
+    @property
+    def single_action_space(self):
+        return self._vecenv.single_action_space
+
+    @property
+    def single_observation_space(self):
+        return self._vecenv.single_observation_space
+
+    @property
+    def policy_env_info(self) -> PolicyEnvInterface:
+        return self._vecenv.policy_env_info
+
+    @property
+    def vecenv(self) -> MettaGridDeviceVecEnv:
+        return self._vecenv
+
+    @property
+    def total_parallel_agents(self) -> int:
+        return self._vecenv.num_agents

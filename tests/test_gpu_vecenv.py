@@ -1,0 +1,141 @@
+"""The device vecenv behind the reference's PufferEnv / pufferlib-vecenv protocol (GPU)."""
+
+import numpy as np
+import pytest
+
+from metta_amd.builder import make_arena
+from metta_amd.compile import compile_game
+from tests.helpers import load_map_pool
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(num_envs=4, max_steps=None, early_reset=False, seed=7):
+    from metta_amd.vecenv import MettaGridDeviceVecEnv
+
+    cfg = make_arena(24)
+    if max_steps is not None:
+        cfg.game.max_steps = max_steps
+    return cfg, MettaGridDeviceVecEnv(cfg, num_envs, maps=load_map_pool()[:4], device=0, seed=seed, early_reset=early_reset)
+
+
+def test_spaces_and_attributes():
+    """reference tests/test_mettagrid_puffer_env.py: spaces and vecenv attributes."""
+    cfg, v = _vec()
+    assert v.single_observation_space.shape == (200, 3) and v.single_observation_space.dtype == np.uint8
+    assert v.single_action_space.n == 5
+    assert v.num_agents == v.agents_per_batch == 4 * 24 and v.num_envs == 96
+    assert v.driver_env is v and v.emulated is False
+    assert v.policy_env_info.action_names == ["noop", "move_north", "move_south", "move_west", "move_east"]
+    v.close()
+
+
+def test_protocol_order_is_enforced():
+    from metta_amd.vecenv import APIUsageError
+
+    cfg, v = _vec()
+    with pytest.raises(APIUsageError):
+        v.recv()
+    v.async_reset(3)
+    with pytest.raises(APIUsageError):
+        v.send(np.zeros(96, np.int32))
+    v.recv()
+    with pytest.raises(APIUsageError):
+        v.recv()
+    with pytest.raises(APIUsageError):
+        v.send(np.zeros(5, np.int32))
+    v.close()
+
+
+def test_reset_seed_determinism_and_seed_plus_i():
+    """reset(seed) twice gives identical trajectories (tests/test_mettagrid_puffer_env.py:123-131); env i uses
+    seed + i (PUF/vector.py:90) -- checked against the oracle."""
+    from oracle.mg_oracle import make_oracle_env
+
+    cfg, v = _vec()
+    maps = load_map_pool()[:4]
+    comp = compile_game(cfg, init_obs_passes=2)
+    rs = np.random.RandomState(0)
+    acts = rs.randint(0, 5, size=(30, 96)).astype(np.int32)
+    runs = []
+    for _ in range(2):
+        obs, infos = v.reset(seed=11)
+        assert infos == []
+        traj = [obs.cpu().numpy().copy()]
+        for t in range(30):
+            o, r, d, tr, infos = v.step(acts[t])
+            traj.append(o.cpu().numpy().copy())
+        runs.append(traj)
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+    oras = [make_oracle_env(comp, comp.encode_map(maps[e % 4]), 11 + e) for e in range(4)]
+    for t in range(30):
+        for e, o in enumerate(oras):
+            o.step(acts[t].reshape(4, 24)[e])
+    final = runs[0][-1].reshape(4, 24, 200, 3)
+    for e, o in enumerate(oras):
+        assert np.array_equal(final[e], o.obs)
+    v.close()
+
+
+@pytest.mark.parametrize("stats_every", [1, 4])
+def test_auto_reset_infos_schema(stats_every):
+    """Episode-end infos carry the StatsTracker schema (PY/envs/stats_tracker.py:26-107;
+    tests/rl/test_training_env_integration.py: infos contain game/agent/attributes)."""
+    cfg, v = _vec(num_envs=3, max_steps=20)
+    v.stats_every = stats_every
+    v.async_reset(5)
+    rs = np.random.RandomState(1)
+    got = []
+    for t in range(70):
+        o, r, d, tr, ta, infos, ids, m = v.recv()
+        got.extend(infos)
+        v.send(rs.randint(0, 5, size=72).astype(np.int32))
+    got.extend(v.recv()[5])
+    assert len(got) >= 6  # 3 envs x at least 2 finished episodes
+    for info in got:
+        assert {"game", "agent", "attributes", "per_label_rewards"} <= set(info)
+        assert info["attributes"]["steps"] == 20 and info["attributes"]["max_steps"] == 20
+        assert info["attributes"]["map_w"] == 62 and info["attributes"]["map_h"] == 62
+        assert info["game"]["objects.wall"] > 1000 and "tokens_written" in info["game"]
+        a = info["agent"]
+        assert abs(a["action.noop.success"] + a.get("action.move.success", 0) + a.get("action.move.failed", 0) - 20) < 1e-4
+        assert "status.max_steps_without_motion" in a
+    v.close()
+
+
+def test_early_reset_desynchronises_first_episode():
+    cfg, v = _vec(num_envs=4, max_steps=50, early_reset=True)
+    np.random.seed(3)
+    v.async_reset(1)
+    first_done = {}
+    for t in range(60):
+        o, r, d, tr, ta, infos, ids, m = v.recv()
+        done = (d.view(4, 24).all(1) | tr.view(4, 24).all(1)).cpu().numpy()
+        for e in range(4):
+            if done[e] and e not in first_done:
+                first_done[e] = t
+                assert tr.view(4, 24)[e].all() or t == 50  # the early cut sets truncations (simulator.py:134-136)
+        v.send(np.zeros(96, np.int32))
+    np.random.seed(3)
+    expected = np.random.randint(1, 51, size=4)
+    assert [first_done[e] for e in range(4)] == expected.tolist()
+    v.close()
+
+
+def test_training_environment_and_device_rollout():
+    import torch
+
+    from metta_amd.rollout import LSTMPolicy, rollout
+    from metta_amd.vecenv import DeviceTrainingEnvironment
+
+    cfg = make_arena(24)
+    env = DeviceTrainingEnvironment(cfg, 8, device=0, seed=0, maps=load_map_pool()[:4], early_reset=False)
+    o, r, d, t, ta, info, ids, mask, n = env.get_observations()
+    assert o.is_cuda and o.shape == (192, 200, 3) and n == 192 and ids == slice(0, 192)
+    env.send_actions(torch.zeros(192, dtype=torch.int32, device="cuda"))
+    assert env.batch_info.num_envs == 8 and env.single_action_space.n == 5
+    policy = LSTMPolicy(200, 5).cuda()
+    steps, secs, state, infos = rollout(env.vecenv, policy, 20)
+    assert steps == 192 * 20 and state[0].shape == (192, 128)
+    env.close()

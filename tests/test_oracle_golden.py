@@ -1,0 +1,112 @@
+"""The CPU oracle against the golden vectors emitted by the REFERENCE (oracle/gen_golden.py), and -- where
+oracle/_ref is built -- live against the reference's compiled core on randomised feature-dense configs."""
+
+import numpy as np
+import pytest
+
+from metta_amd.builder import make_arena, make_navigation
+from metta_amd.compile import compile_game
+from oracle.mg_oracle import make_oracle_env
+from tests.fuzz_configs import fuzz_actions, rand_cfg
+from tests.helpers import digest, fixture_actions, fixture_grid, load_fixture, stats_equal
+
+
+@pytest.mark.parametrize("name", ["arena24_seed0", "arena24_seed1", "arena24_seed42"])
+def test_oracle_matches_reference_fixture_arena(name):
+    z, meta = load_fixture(name)
+    comp = compile_game(make_arena(24), init_obs_passes=2)
+    env = make_oracle_env(comp, comp.encode_map(fixture_grid(z, meta)), meta["seed"])
+    assert np.array_equal(env.obs, z["obs0"])
+    acts = fixture_actions(meta, 24)
+    snaps = set(meta["snap_steps"])
+    done_step = -1
+    for t in range(len(acts)):
+        env.step(acts[t])
+        assert digest(env.obs) == int(z["obs_digest"][t]), f"{name}: obs digest differs at step {t + 1}"
+        assert digest(env.rewards) == int(z["rew_digest"][t]), f"{name}: reward digest differs at step {t + 1}"
+        assert digest(env.action_success) == int(z["succ_digest"][t])
+        if (t + 1) in snaps:
+            assert np.array_equal(env.obs, z[f"snap_{t + 1}"])
+        if done_step < 0 and (env.terminals.all() or env.truncations.all()):
+            done_step = t + 1
+    assert done_step == meta["done_step"]
+    assert np.array_equal(env.obs, z["obs_final"])
+    assert np.array_equal(env.episode_rewards, z["episode_rewards"])
+    st = env.agent_state()
+    assert np.array_equal(st[:, :2], z["agent_rc"])
+    for a, inv in enumerate(meta["agent_inv"]):
+        assert [[int(st[a, 9 + 2 * k]), int(st[a, 10 + 2 * k])] for k in range(st[a, 8])] == inv
+    assert stats_equal(env.get_episode_stats(), meta["stats"]) is None
+
+
+def test_oracle_matches_reference_fixture_navigation():
+    z, meta = load_fixture("navigation4_seed3")
+    cfg = make_navigation(4)
+    cfg.game.max_steps = meta["max_steps"]
+    comp = compile_game(cfg, init_obs_passes=2)
+    assert len(comp.action_names) == 157  # noop + 4 moves + 152 change_vibe
+    env = make_oracle_env(comp, comp.encode_map(fixture_grid(z, meta)), meta["seed"])
+    assert np.array_equal(env.obs, z["obs0"])
+    acts = fixture_actions(meta, 4)
+    for t in range(len(acts)):
+        env.step(acts[t])
+        assert digest(env.obs) == int(z["obs_digest"][t])
+        assert digest(env.rewards) == int(z["rew_digest"][t])
+    assert np.array_equal(env.obs, z["obs_final"])
+    assert stats_equal(env.get_episode_stats(), meta["stats"]) is None
+
+
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_oracle_vs_reference_core_fuzz(seed):
+    """Live, step-by-step, bit-for-bit against the reference's compiled C++ core (chests, damage, attack,
+    transfer, partial usage, modifiers, ... -- tests/fuzz_configs.py)."""
+    from oracle.ref_bridge import RefEnv, have_reference
+
+    if not have_reference():
+        pytest.skip("oracle/_ref not built (run `make -C oracle ref` where /root/reference exists)")
+    rs = np.random.RandomState(seed)
+    cfg = rand_cfg(rs, device_safe=False)
+    game = cfg.game
+    passes = int(rs.randint(1, 3))
+    comp = compile_game(cfg, init_obs_passes=passes)
+    grid = game.map_builder.build(np.random.default_rng(seed))
+    ref = RefEnv(game, grid, seed, with_buffers=(passes == 2))
+    ora = make_oracle_env(comp, comp.encode_map(grid), seed)
+    assert np.array_equal(ref.obs, ora.obs)
+    nA = len(comp.action_names)
+    for t in range(200):
+        acts = fuzz_actions(rs, game, nA)
+        if rs.randint(40) == 0:
+            ag = int(rs.randint(game.num_agents))
+            inv = {int(rs.randint(len(game.resource_names))): int(rs.randint(0, 400)) for _ in range(rs.randint(0, 4))}
+            ref.env.set_inventory(ag, inv)
+            ora.set_inventory(ag, inv)
+        ref.step(acts)
+        ora.step(acts)
+        assert np.array_equal(ref.obs, ora.obs), f"obs differ at step {t}"
+        assert np.array_equal(ref.rewards, ora.rewards), f"rewards differ at step {t}"
+        assert np.array_equal(ref.terminals, ora.terminals.astype(bool))
+        assert np.array_equal(ref.truncations, ora.truncations.astype(bool))
+        assert np.array_equal(np.array(ref.env.action_success()), ora.action_success.astype(bool))
+    assert stats_equal(ref.env.get_episode_stats(), ora.get_episode_stats()) is None
+    assert np.array_equal(ref.env.get_episode_rewards(), ora.episode_rewards)
+    go = ref.env.grid_objects()
+    st = ora.agent_state()
+    for o in go.values():
+        if "agent_id" in o:
+            row = st[o["agent_id"]]
+            assert (o["r"], o["c"], o["freeze_remaining"], o["vibe"], o["id"]) == (row[0], row[1], row[4], row[5], row[7])
+            assert list(o["inventory"].items()) == [(int(row[9 + 2 * k]), int(row[10 + 2 * k])) for k in range(row[8])]
+
+
+def test_bridge_matches_reference_python_converter_shapes():
+    """The config mirror reproduces the reference's ids: action order, feature ids, type ids, tags."""
+    cfg = make_arena(24)
+    comp = compile_game(cfg)
+    assert comp.action_names == ["noop", "move_north", "move_south", "move_west", "move_east"]
+    assert comp.action_names[0] == "noop"  # reference tests/test_actions.py:280
+    f = {v: k for k, v in comp.feature_names.items()}
+    assert f["agent:group"] == 0 and f["remaining_uses"] == 11 and f["inv:ore_red"] == 12 and f["inv:ore_red:p1"] == 13
+    assert len(comp.feature_names) == 12 + 2 * 10 + 2 * 10  # 52 feature ids
+    assert comp.tag_names == ["agent", "armory", "assembler", "generator_red", "lasery", "mine_red", "wall"]
+    assert comp.object_type_names[0] == "agent" and comp.object_type_names[1:] == sorted(cfg.game.objects.keys())
