@@ -91,6 +91,7 @@ struct KArgs {
 
 struct Lds {
   int* dc;
+  int* tmp;  // [8][96] scratch ints: one slot per concurrently acting lane
   uint16_t* grid;
   DAgent* ag;
   DAsm* as;
@@ -122,7 +123,11 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     return at;
   };
   size_t dco = take((size_t)dcw * 4);
-  if (l) l->dc = (int*)(base + dco);
+  size_t tmpo = take(8 * 96 * 4);
+  if (l) {
+    l->dc = (int*)(base + dco);
+    l->tmp = (int*)(base + tmpo);
+  }
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
@@ -540,6 +545,7 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e,
   cx.TW = a.TW;
   cx.gd = l.gd;
   cx.dirty_amt = l.dirty_amt;
+  cx.tmp = l.tmp;
   cx.dirty_misc = l.dirty_misc;
   cx.H = a.H; cx.W = a.W; cx.A = a.A; cx.NA = a.NAmax; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG;
   cx.step = step;
@@ -718,29 +724,62 @@ __device__ inline void mg_pending_uses(const KArgs& a, const Lds& l, Ctx& cx, in
   mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);  // env.step was already advanced by the fast kernel
   cx.grid = nullptr;
   __syncthreads();
+  MG_STAMP(9);
+  // Uses that share neither an agent nor the assembler commute, so they run on separate lanes; conflicting ones are
+  // ordered into successive rounds (round of use q = 1 + the latest round among earlier conflicting uses).
+  const uint8_t* recs = a.pend + (size_t)e * a.A * 32;
+  uint8_t* rounds = (uint8_t*)l.order;  // [A] bytes (the order array is unused on this path)
   if (tid == 0) {
-    const uint8_t* rec = a.pend + (size_t)e * a.A * 32;
-    for (int q = 0; q < count; q++, rec += 32) {
-      int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
-      int act = (int)(rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((uint32_t)rec[7] << 24));
-      int near[8];
-      uint8_t vibes[8];
-      for (int i = 0; i < 8; i++) {
-        near[i] = rec[8 + i];
-        vibes[i] = rec[16 + i];
+    int max_round = 0;
+    for (int q = 0; q < count; q++) {
+      const uint8_t* rq = recs + q * 32;
+      unsigned long long mq = 0;
+      for (int i = 0; i < rq[1]; i++) mq |= 1ull << rq[8 + i];
+      int aq = rq[2] | (rq[3] << 8), rd = 0;
+      for (int p2 = 0; p2 < q; p2++) {
+        const uint8_t* rp = recs + p2 * 32;
+        unsigned long long mp = 0;
+        for (int i = 0; i < rp[1]; i++) mp |= 1ull << rp[8 + i];
+        int ap = rp[2] | (rp[3] << 8);
+        if ((mp & mq) != 0 || ap == aq) rd = max(rd, rounds[p2] + 1);
       }
-      bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
-      if (ok) {
-        l.ag[actor].succ[MG_ACT_MOVE] += 1;
-        a.exec[(size_t)e * a.A + actor] = act;
-        a.success[(size_t)e * a.A + actor] = 1;
-      } else {
-        l.ag[actor].fail[MG_ACT_MOVE] += 1;
-      }
+      rounds[q] = (uint8_t)rd;
+      max_round = max(max_round, rd);
     }
-    l.flags[2] = cx.asm_dirty;
+    l.flags[0] = max_round;
+    l.flags[2] = 0;
   }
   __syncthreads();
+  const int max_round = l.flags[0];
+  for (int rd = 0; rd <= max_round; rd++) {
+    for (int q0 = 0; q0 < count; q0 += 8) {  // 8 scratch slots
+      int q = q0 + tid;
+      if (tid < 8 && q < count && rounds[q] == rd) {
+        const uint8_t* rec = recs + q * 32;
+        int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
+        int act = (int)(rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((uint32_t)rec[7] << 24));
+        cx.tmp = l.tmp + tid * 96;
+        int* near = cx.tmp;
+        uint8_t* vibes = (uint8_t*)(cx.tmp + 8);
+        for (int i = 0; i < 8; i++) {
+          near[i] = rec[8 + i];
+          vibes[i] = rec[16 + i];
+        }
+        bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
+        if (ok) {
+          l.ag[actor].succ[MG_ACT_MOVE] += 1;
+          a.exec[(size_t)e * a.A + actor] = act;
+          a.success[(size_t)e * a.A + actor] = 1;
+        } else {
+          l.ag[actor].fail[MG_ACT_MOVE] += 1;
+        }
+        if (cx.asm_dirty) l.flags[2] = 1;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  MG_STAMP(10);
   mg_flush_stats(a, l, cx, e, tid, nt);
   uint4* wd = (uint4*)(a.agents + (size_t)e * a.A);
   const uint4* ws = (const uint4*)l.ag;
@@ -750,6 +789,7 @@ __device__ inline void mg_pending_uses(const KArgs& a, const Lds& l, Ctx& cx, in
     const uint4* ws2 = (const uint4*)l.as;
     for (int i = tid; i < a.NAmax; i += nt) wd2[i] = ws2[i];
   }
+  MG_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1045,8 +1085,9 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   Lds l;
   mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
   if (a.fast && a.mode[e] == 0) return;  // the fast kernel finished this environment's step
+  MG_STAMP(8);
   if (DCL) {
-    for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
+    for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
     a.dc = l.dc;
     __syncthreads();
   }
@@ -1167,7 +1208,7 @@ __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   Lds l;
   mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
   if (DCL) {
-    for (int i = tid; i < a.dc_words; i += nt) l.dc[i] = a.dc[i];
+    for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
     a.dc = l.dc;
   }
   MG_STAMP(0);
@@ -1278,6 +1319,7 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   cx.astats = a.astats + ((size_t)e * a.A + agent) * a.SA;  // record 0 of this context is `agent`
   cx.atouched = a.atouched + ((size_t)e * a.A + agent) * a.TW;
   cx.TW = a.TW;
+  cx.tmp = nullptr;
   cx.dirty_amt = &dirty[0]; cx.dirty_misc = &dirty[1];
   cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
   cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A};
@@ -1415,6 +1457,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
     k.fast = ok ? 1 : 0;
   }
   std::vector<int32_t> dcfg = mg_build_dcfg(c);
+  while (dcfg.size() % 4) dcfg.push_back(0);  // staged into LDS with 16-byte copies
   int* d_dc = nullptr;
   if (dalloc(h.get(), &d_dc, dcfg.size())) return 1;
   HIPCHK(hipMemcpy(d_dc, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice));

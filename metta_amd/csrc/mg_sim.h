@@ -70,6 +70,7 @@ struct Ctx {
   float* astats;                      // this env's [A][SA] stat slots in HBM (rare events add to them directly)
   uint32_t* atouched;                 // this env's [A][TW] explicit touched bits
   int TW;
+  int* tmp;                           // [96] LDS scratch ints of the acting thread (lists of the assembler path)
   int* gd;                            // [SG] game stat deltas of this step
   uint32_t* dirty_amt;                // [A] bit r: <r>.amount was set this step
   uint32_t* dirty_misc;               // [A] bit0 diversity, bit1 max_steps_without_motion
@@ -100,20 +101,16 @@ __device__ __forceinline__ const int* wall_rec(const int* dc, int w) { return dc
 
 // ---- inventory: unordered_map<uint8,uint16> order emulation (hashtable.h:1888-1912) -------
 __device__ inline int mg_next_bkt(DAgent* a, int n) {
-  const int fast[14] = {2, 2, 2, 3, 5, 5, 7, 7, 11, 11, 11, 11, 13, 13};
+  int r;
   if (n < 14) {
     if (n == 0) return 1;
-    a->next_resize = (uint8_t)fast[n];
-    return fast[n];
+    r = (int)((0xDDBBBB77553222ull >> (4 * n)) & 0xF);  // __fast_bkt[] = 2,2,2,3,5,5,7,7,11,11,11,11,13,13
+  } else {
+    r = n <= 17 ? 17 : n <= 19 ? 19 : n <= 23 ? 23 : n <= 29 ? 29 : n <= 31 ? 31 : n <= 37 ? 37 : n <= 41 ? 41
+        : n <= 43 ? 43 : n <= 47 ? 47 : n <= 53 ? 53 : 59;
   }
-  const int primes[10] = {17, 19, 23, 29, 31, 37, 41, 43, 47, 53};
-  for (int i = 0; i < 10; i++)
-    if (primes[i] >= n) {
-      a->next_resize = (uint8_t)primes[i];
-      return primes[i];
-    }
-  a->next_resize = 59;
-  return 59;
+  a->next_resize = (uint8_t)r;
+  return r;
 }
 __device__ inline void mg_insert_node(DAgent* a, int k) {
   int nb = a->nb, b = k % nb, n = a->n_items, pos = 0;
@@ -130,12 +127,15 @@ __device__ inline void mg_insert_node(DAgent* a, int k) {
   a->n_items = (uint8_t)(n + 1);
 }
 __device__ inline void mg_rehash(DAgent* a, int m) {
-  uint8_t old[MGD_MAX_R];
+  unsigned long long o0 = 0, o1 = 0;  // the 16-entry order list, packed (no private array -> no scratch)
   int n = a->n_items;
-  for (int i = 0; i < n; i++) old[i] = a->order[i];
+  for (int i = 0; i < n; i++) {
+    unsigned long long v = a->order[i];
+    if (i < 8) o0 |= v << (8 * i); else o1 |= v << (8 * (i - 8));
+  }
   a->n_items = 0;
   a->nb = (uint8_t)m;
-  for (int i = 0; i < n; i++) mg_insert_node(a, old[i]);
+  for (int i = 0; i < n; i++) mg_insert_node(a, (int)(((i < 8 ? o0 >> (8 * i) : o1 >> (8 * (i - 8)))) & 0xFF));
 }
 __device__ inline void mg_map_insert(DAgent* a, int k) {  // operator[] on an absent key
   int n_elt = a->n_items;
@@ -266,20 +266,19 @@ __device__ inline int inv_update(Ctx& cx, int ai, int item, int delta, bool igno
   return mg_inv_update<0>(cx, ai, item, delta, ignore);
 }
 
-// HasInventory::shared_update (has_inventory.cpp:7-73) over agent inventories
+// HasInventory::shared_update (has_inventory.cpp:7-73) over the agent inventories list[0..n) (n <= 8).
+// The reference's "inventories to consider" vectors are sub-sequences of the list in list order, so they are kept as
+// bitmasks over list positions.
 __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item, int delta) {
   if (n == 0) return 0;
-  int consider[8], next[8];
-  int n_consider = 0, n_next = n;
-  for (int i = 0; i < n; i++) next[i] = list[i];
+  uint32_t consider, next = (1u << n) - 1u;
   int delta_remaining = delta, num_remaining = n;
   int per = delta_remaining / num_remaining;
   do {
-    n_consider = n_next;
-    for (int i = 0; i < n_next; i++) consider[i] = next[i];
-    n_next = 0;
-    for (int i = 0; i < n_consider; i++) {
-      int ai = consider[i];
+    consider = next;
+    next = 0;
+    for (uint32_t m = consider; m; m &= m - 1) {
+      int pos = __ffs(m) - 1, ai = list[pos];
       bool now;
       if (delta_remaining > 0)
         now = mg_free_space(cx, &cx.ag[ai], item) <= per;
@@ -290,38 +289,44 @@ __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item
         num_remaining--;
         if (num_remaining > 0) per = delta_remaining / num_remaining;
       } else {
-        next[n_next++] = ai;
+        next |= 1u << pos;
       }
     }
-  } while (n_consider != n_next);
+  } while (consider != next);
   if (num_remaining == 0) return delta - delta_remaining;
-  for (int i = n_consider - 1; i >= 0; i--) {
+  // reverse order, so that earlier inventories get the remainder
+  int i = __popc(consider) - 1;
+  for (uint32_t m = consider; m; i--) {
+    int pos = 31 - __clz(m);
+    m &= ~(1u << pos);
     int d = delta_remaining / (i + 1);
-    delta_remaining -= inv_update(cx, consider[i], item, d);
+    delta_remaining -= inv_update(cx, list[pos], item, d);
   }
   return delta - delta_remaining;
 }
 
 // ---- assembler ---------------------------------------------------------------------------------------------
 // Protocol lookup (assembler.hpp:378-408) from the vibes of the surrounding agents (any order; zeros ignored) and
-// their number.  Returns the protocol record offset or -1.
-__device__ inline int mg_select_protocol(const int* dc, int cfg, const uint8_t* near_vibes, int n_agents, bool clipped) {
-  uint8_t vibes[8];
-  int nv = 0;
-  for (int q = 0; q < n_agents && q < 8; q++) {
-    uint8_t v = near_vibes[q];
-    if (v != 0) {  // insertion sort (std::sort of the vibe vector, assembler.hpp:326-331)
-      int p = nv++;
-      while (p > 0 && vibes[p - 1] > v) {
-        vibes[p] = vibes[p - 1];
-        p--;
-      }
-      vibes[p] = v;
-    }
-  }
+// their number (byte q of `packed_vibes` = vibe of the q-th surrounding agent).  Returns the record offset or -1.
+__device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long long packed_vibes, int n_agents,
+                                         bool clipped) {
   if (clipped) return -1;  // unclip protocols only come from a Clipper (out of scope)
+  // key = the non-zero vibes sorted ascending, 8 bits each (assembler.hpp:326-331): selection sort on the packed bytes
   unsigned long long key = 0;
-  for (int i = 0; i < nv; i++) key = (key << 8) | vibes[i];
+  uint32_t used = 0;
+  for (int t = 0; t < 8; t++) {
+    int best = -1, bv = 256;
+    for (int q = 0; q < n_agents && q < 8; q++) {
+      int v = (int)((packed_vibes >> (8 * q)) & 0xFF);
+      if (!((used >> q) & 1u) && v != 0 && v < bv) {
+        bv = v;
+        best = q;
+      }
+    }
+    if (best < 0) break;
+    used |= 1u << best;
+    key = (key << 8) | (unsigned long long)bv;
+  }
   const int* rec = asm_rec(dc, cfg);
   int nk = rec[AR_N_KEYS], ok = rec[AR_OFF_KEYS], pt = rec[AR_OFF_PTABLE];
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -342,7 +347,7 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, const uint8_t* 
 // Assembler::get_current_protocol on the grid as it stands (assembler.hpp:353-408).
 __device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, CellCodec codec, int H,
                                           int W, int ar, int ac, int cfg, bool clipped) {
-  uint8_t vibes[8];
+  unsigned long long vibes = 0;
   int n_agents = 0;
   for (int i = -1; i <= 1; i++)
     for (int j = -1; j <= 1; j++) {
@@ -350,7 +355,10 @@ __device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, c
       int rr = ar + i, cc = ac + j;
       if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
       uint16_t cv = grid[rr * W + cc];
-      if (codec.is_agent(cv)) vibes[n_agents++] = ag[codec.agent_idx(cv)].vibe;
+      if (codec.is_agent(cv)) {
+        vibes |= (unsigned long long)ag[codec.agent_idx(cv)].vibe << (8 * n_agents);
+        n_agents++;
+      }
     }
   return mg_select_protocol(dc, cfg, vibes, n_agents, clipped);
 }
@@ -375,10 +383,12 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
   uint32_t remaining = as->cooldown_end <= cx.step ? 0 : as->cooldown_end - cx.step;
   bool partial = rec[AR_ALLOW_PARTIAL] != 0;
   if (remaining > 0 && !partial) return false;
-  int po = mg_select_protocol(dc, info.z, near_vibes, nn, as->clipped != 0);
+  unsigned long long pv = 0;
+  for (int q = 0; q < nn && q < 8; q++) pv |= (unsigned long long)near_vibes[q] << (8 * q);
+  int po = mg_select_protocol(dc, info.z, pv, nn, as->clipped != 0);
   if (po < 0) return false;
   // protocol_to_use as (item, amount) lists
-  int in_k[MGD_MAX_R], in_v[MGD_MAX_R], out_k[MGD_MAX_R], out_v[MGD_MAX_R];
+  int* in_k = cx.tmp + 16; int* in_v = cx.tmp + 32; int* out_k = cx.tmp + 48; int* out_v = cx.tmp + 64;
   int n_in, n_out;
   int oin = dc[po + PR_OFF_IN], oout = dc[po + PR_OFF_OUT];
   bool orig_pos_out = false;
@@ -424,24 +434,24 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
     if (total < (in_v[i] & 0xFFFF)) return false;
   }
   // get_output_inventories (assembler.hpp:198-223)
-  int outs[8], no = 0;
+  int* outs = cx.tmp + 80;
+  int no = 0;
   int ov = dc[po + PR_OFF_VIBES], nvib = L_n(dc, ov);
   if (nvib <= 1) {
     outs[no++] = ai_actor;
   } else {
-    int cnt[8];  // remaining required count per distinct position in the vibes list
-    for (int i = 0; i < nvib && i < 8; i++) cnt[i] = 1;
+    uint32_t open_slots = (1u << (nvib < 8 ? nvib : 8)) - 1u;  // required vibes not yet matched (one bit per entry)
     for (int q = 0; q < nn; q++) {
       uint8_t v = near_vibes[q];
       if (v == 0) continue;
       int slot = -1;
       for (int i = 0; i < nvib && i < 8; i++)
-        if (L_at(dc, ov, i) == v && cnt[i] > 0) {
+        if (L_at(dc, ov, i) == v && ((open_slots >> i) & 1u)) {
           slot = i;
           break;
         }
       if (slot < 0) continue;
-      cnt[slot] = 0;
+      open_slots &= ~(1u << slot);
       outs[no++] = near[q];
       if (no >= nvib) break;
     }
@@ -467,7 +477,7 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
   for (int i = 0; i < n_in; i++) mg_shared_update(cx, near, nn, in_k[i], -in_v[i]);
   for (int i = 0; i < n_out; i++) {
     int distributed = mg_shared_update(cx, outs, no, out_k[i], out_v[i]);
-    if (distributed > 0) cx.gd[cx.GS.assembler_created(out_k[i])] += distributed;
+    if (distributed > 0) atomicAdd(&cx.gd[cx.GS.assembler_created(out_k[i])], distributed);  // LDS; uses may run on several lanes
   }
   as->cooldown_duration = (uint32_t)dc[po + PR_COOLDOWN];
   as->cooldown_end = cx.step + as->cooldown_duration;
@@ -485,23 +495,31 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
   int4 info = cx.asm_info[asm_idx];
   int ar = info.x, ac = info.y;
   const DAgent* actor = &cx.ag[ai_actor];
-  int pr[8], pc[8], np = 0, start = -1;
-  for (int i = -1; i <= 1; i++)
-    for (int j = -1; j <= 1; j++) {
-      if (i == 0 && j == 0) continue;
-      int rr = ar + i, cc = ac + j;
-      if (rr < 0 || cc < 0 || rr >= cx.H || cc >= cx.W) continue;
-      if (rr == actor->r && cc == actor->c && start < 0) start = np;
-      pr[np] = rr;
-      pc[np] = cc;
-      np++;
-    }
+  // in-map ring positions NW,N,NE,W,E,SW,S,SE (assembler.hpp:30-45) as a bitmask; `start` = the actor's index
+  uint32_t vmask = 0;
+  int np = 0, start = -1;
+  for (int q = 0; q < 8; q++) {
+    int o9 = q < 4 ? q : q + 1;
+    int rr = ar + o9 / 3 - 1, cc = ac + o9 % 3 - 1;
+    if (rr < 0 || cc < 0 || rr >= cx.H || cc >= cx.W) continue;
+    if (rr == actor->r && cc == actor->c && start < 0) start = np;
+    vmask |= 1u << q;
+    np++;
+  }
   if (start < 0) return false;  // reference throws; cannot happen for a move into the assembler
-  int near[8], nn = 0;
-  uint8_t vibes[8];
-  for (int q = 0; q < np; q++) {
-    int p = (start + q) % np;
-    uint16_t cv = cx.grid[pr[p] * cx.W + pc[p]];
+  int* near = cx.tmp;
+  uint8_t* vibes = (uint8_t*)(cx.tmp + 8);
+  int nn = 0;
+  for (int t = 0; t < np; t++) {
+    int want = (start + t) % np;  // index among the in-map positions
+    int q = 0;
+    for (int seen = 0; q < 8; q++)
+      if ((vmask >> q) & 1u) {
+        if (seen == want) break;
+        seen++;
+      }
+    int o9 = q < 4 ? q : q + 1;
+    uint16_t cv = cx.grid[(ar + o9 / 3 - 1) * cx.W + (ac + o9 % 3 - 1)];
     if (cx.cc.is_agent(cv)) {
       near[nn] = cx.cc.agent_idx(cv);
       vibes[nn] = cx.ag[near[nn]].vibe;

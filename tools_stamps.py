@@ -18,3 +18,6 @@ d=np.diff(out[:,:7].astype(np.int64),axis=1)
 print("phase medians (stamp units):", np.median(d,axis=0), "mean", d.mean(axis=0))
 print("total per block median", np.median(out[:,6].astype(np.int64)-out[:,0].astype(np.int64)))
 print("kernel span", int(out[:,6].max()-out[:,0].min()))
+m = out[:,8] != 0
+u = out[m][:, 8:12].astype(np.int64)
+print("uses envs", int(m.sum()), "of", E, " phases (stage, serial, flush) median:", np.median(np.diff(u,axis=1),axis=0), "max:", np.diff(u,axis=1).max(axis=0))
