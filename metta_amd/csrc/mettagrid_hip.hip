@@ -219,18 +219,57 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
   }
 }
 
+struct EncCfg {  // per-kernel constants of the encoder, read from the config stream once (not per agent)
+  int oh, ow, hr, wr, P, T, H, W;
+  uint32_t center;
+  int g_completion, g_last_action, g_last_reward, g_goal, g_compass;
+  uint32_t f_completion, f_last_action, f_last_reward, f_goal, f_compass;
+  int pct;
+};
+__device__ inline EncCfg mg_enc_cfg(const KArgs& a, uint32_t step) {
+  const int* dc = a.dc;
+  EncCfg c;
+  c.oh = dc[DC_OBS_H]; c.ow = dc[DC_OBS_W]; c.hr = c.oh >> 1; c.wr = c.ow >> 1; c.P = dc[DC_PATTERN_N]; c.T = a.T;
+  c.H = a.H; c.W = a.W;
+  c.center = (uint32_t)((c.hr << 4) | (c.wr & 0x0F));
+  c.g_completion = dc[DC_G_COMPLETION]; c.g_last_action = dc[DC_G_LAST_ACTION]; c.g_last_reward = dc[DC_G_LAST_REWARD];
+  c.g_goal = dc[DC_G_GOAL]; c.g_compass = dc[DC_G_COMPASS];
+  c.f_completion = (uint32_t)dc[DC_FID0 + MG_F_COMPLETION]; c.f_last_action = (uint32_t)dc[DC_FID0 + MG_F_LAST_ACTION];
+  c.f_last_reward = (uint32_t)dc[DC_FID0 + MG_F_LAST_REWARD]; c.f_goal = (uint32_t)dc[DC_FID0 + MG_F_GOAL];
+  c.f_compass = (uint32_t)dc[DC_FID0 + MG_F_COMPASS];
+  int ms = dc[DC_MAX_STEPS];
+  c.pct = 0;
+  if (ms > 0) c.pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
+  return c;
+}
+
+#define MG_MAX_ROUNDS 4  // ceil(15 * 15 / 64): observation windows are at most 15 x 15
+
 // One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
 // MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
-__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t step, int ai, int action, uint8_t* row,
-                                      int lane) {
-  const int* dc = a.dc;
+template <int NR>
+__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, int ai, int action,
+                                      uint8_t* __restrict__ row, const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
   const DAgent* me = &l.ag[ai];
-  const int T = a.T, oh = dc[DC_OBS_H], ow = dc[DC_OBS_W], hr = oh >> 1, wr = ow >> 1;
-  const int ar = me->r, ac = me->c, H = a.H, W = a.W;
+  const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
+  const int ar = me->r, ac = me->c;
+  // window lookups of all rounds first (independent LDS reads overlap).  Window offsets never exceed the radius, so
+  // "inside the window and the map" is just "inside the map".
+  uint32_t meta[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    meta[q] = 0;
+    int p = q * 64 + lane;
+    int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
+    if (p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) {
+      uint16_t cv = l.grid[r * W + c];
+      if (cv != 0) meta[q] = l.ocnt[(int)cv - 1];  // heap offset | token count << 16
+    }
+  }
   int base = 0;
   if (lane == 0) {  // global tokens + compass at/around the centre (a handful; one lane)
-    uint8_t loc = (uint8_t)((hr << 4) | (wr & 0x0F));
-    auto put = [&](uint8_t lc, int f, int v) {
+    const uint8_t loc = (uint8_t)ec.center;
+    auto put = [&](uint8_t lc, uint32_t f, int v) {
       if (base < T) {
         row[base * 3 + 0] = lc;
         row[base * 3 + 1] = (uint8_t)f;
@@ -238,46 +277,27 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t ste
       }
       base++;
     };
-    if (dc[DC_G_COMPLETION]) {
-      int pct = 0, ms = dc[DC_MAX_STEPS];
-      if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
-      put(loc, dc[DC_FID0 + MG_F_COMPLETION], pct);
-    }
-    if (dc[DC_G_LAST_ACTION]) put(loc, dc[DC_FID0 + MG_F_LAST_ACTION], action);
+    if (ec.g_completion) put(loc, ec.f_completion, ec.pct);
+    if (ec.g_last_action) put(loc, ec.f_last_action, action);
     // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
-    if (dc[DC_G_LAST_REWARD]) put(loc, dc[DC_FID0 + MG_F_LAST_REWARD], 0);
-    if (dc[DC_G_GOAL]) {
+    if (ec.g_last_reward) put(loc, ec.f_last_reward, 0);
+    if (ec.g_goal) {
+      const int* dc = a.dc;
       int og = group_rec(dc, me->group)[GR_OFF_GOAL], ng = L_n(dc, og);
-      for (int i = 0; i < ng; i++) put(loc, dc[DC_FID0 + MG_F_GOAL], L_at(dc, og, i));
+      for (int i = 0; i < ng; i++) put(loc, ec.f_goal, L_at(dc, og, i));
     }
-    if (dc[DC_G_COMPASS]) {
+    if (ec.g_compass) {
       int dr = H / 2 - ar, dcc = W / 2 - ac;
       int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
       int orr = hr + sr, occ = wr + sc;
-      if ((sr != 0 || sc != 0) && orr >= 0 && orr < oh && occ >= 0 && occ < ow)
-        put((uint8_t)((orr << 4) | (occ & 0x0F)), dc[DC_FID0 + MG_F_COMPASS], 1);
+      if ((sr != 0 || sc != 0) && orr >= 0 && orr < ec.oh && occ >= 0 && occ < ec.ow)
+        put((uint8_t)((orr << 4) | (occ & 0x0F)), ec.f_compass, 1);
     }
   }
-  base = __shfl(base, 0, 64);
-  const int P = dc[DC_PATTERN_N];
-  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
-  const int r_end = min(ar + hr + 1, H), c_end = min(ac + wr + 1, W);
-  for (int p0 = 0; p0 < P; p0 += 64) {
-    int p = p0 + lane;
-    int cnt = 0, obj = 0;
-    uint32_t pk = 0;
-    if (p < P) {
-      pk = l.pat[p];
-      int r = ar + (int)(pk & 0xFF) - 8, c = ac + (int)((pk >> 8) & 0xFF) - 8;
-      if (r >= r_start && r < r_end && c >= c_start && c < c_end) {
-        uint16_t cv = l.grid[r * W + c];
-        if (cv != 0) {
-          uint32_t meta = l.ocnt[(int)cv - 1];
-          obj = (int)(meta & 0xFFFF);  // heap offset of the object's token list
-          cnt = (int)(meta >> 16);
-        }
-      }
-    }
+  base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int cnt = (int)(meta[q] >> 16);
     // exclusive prefix sum of cnt over the wave: ones via mbcnt, the few multi-token objects by a uniform loop
     unsigned long long any = __ballot(cnt > 0);
     unsigned long long big = __ballot(cnt > 1);
@@ -292,15 +312,18 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, uint32_t ste
     }
     off += base;
     if (cnt > 0 && off < T) {
-      const uint16_t* src = l.heap + obj;
-      uint8_t loc = (uint8_t)(pk >> 16);
-      int n = min(cnt, T - off);
-      uint8_t* dst = row + off * 3;
-      for (int k = 0; k < n; k++) {
-        uint16_t fv = src[k];
-        dst[k * 3 + 0] = loc;
-        dst[k * 3 + 1] = (uint8_t)(fv & 0xFF);
-        dst[k * 3 + 2] = (uint8_t)(fv >> 8);
+      // token lists start 8-byte aligned and are padded to x4 tokens: read 4 tokens per LDS access
+      const uint2* __restrict__ src = (const uint2*)(l.heap + (meta[q] & 0xFFFF));
+      const uint8_t loc = (uint8_t)(pk[q] >> 16);
+      const int n = min(cnt, T - off);
+      uint8_t* __restrict__ dst = row + off * 3;
+      for (int k = 0; k < n; k += 4) {
+        uint2 v = src[k >> 2];
+        uint32_t t0 = v.x & 0xFFFF, t1 = v.x >> 16, t2 = v.y & 0xFFFF, t3 = v.y >> 16;
+        dst[k * 3 + 0] = loc; dst[k * 3 + 1] = (uint8_t)t0; dst[k * 3 + 2] = (uint8_t)(t0 >> 8);
+        if (k + 1 < n) { dst[k * 3 + 3] = loc; dst[k * 3 + 4] = (uint8_t)t1; dst[k * 3 + 5] = (uint8_t)(t1 >> 8); }
+        if (k + 2 < n) { dst[k * 3 + 6] = loc; dst[k * 3 + 7] = (uint8_t)t2; dst[k * 3 + 8] = (uint8_t)(t2 >> 8); }
+        if (k + 3 < n) { dst[k * 3 + 9] = loc; dst[k * 3 + 10] = (uint8_t)t3; dst[k * 3 + 11] = (uint8_t)(t3 >> 8); }
       }
     }
     base += total;
@@ -315,13 +338,19 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
   uint8_t* row = l.rows + (size_t)wave * a.ROWB;
   const int row_bytes = a.T * 3;
+  const EncCfg ec = mg_enc_cfg(a, step);
+  uint32_t pk[MG_MAX_ROUNDS];
+#pragma unroll
+  for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q * 64 + lane) < ec.P ? l.pat[q * 64 + lane] : 0u;
   for (int ai = wave; ai < a.A; ai += nwaves) {
     for (int i = lane; i < (a.ROWB >> 2); i += 64) ((uint32_t*)row)[i] = 0xFFFFFFFFu;
     __builtin_amdgcn_wave_barrier();
-    int attempted = mg_encode_agent(a, l, step, ai, exec ? exec[ai] : 0, row, lane);
+    const int act = exec ? exec[ai] : 0;
+    int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, ai, act, row, pk, lane)
+                                : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, ai, act, row, pk, lane);
     if (lane == 0) l.tok_att[ai] = attempted;
     __builtin_amdgcn_wave_barrier();
-    if (write_global) {
+    if (write_global && !(a.diag & 1)) {
       uint8_t* dst = a.obs + ((size_t)e * a.A + ai) * (size_t)row_bytes;
       if ((row_bytes & 3) == 0) {
         uint32_t* d32 = (uint32_t*)dst;
@@ -1576,6 +1605,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
     TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
   }
   if (TSW > 255 || TSA > 255 || TSS > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
+  TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time
   const int NOBJ = (int)c.walls.size() + c.A + NAmax;
   const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS;
   const int NP = c.obs_h * c.obs_w;
