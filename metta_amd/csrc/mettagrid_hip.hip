@@ -29,12 +29,13 @@
 #define MG_WIN_MARGIN 32
 #define MG_STAMP(slot)                                                     \
   do {                                                                    \
-    if (a.dbg && threadIdx.x == 0) a.dbg[(size_t)blockIdx.x * 16 + (slot)] = clock64(); \
+    if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + (slot)] = clock64(); \
   } while (0)
 #define MG_DC_LDS_MAX_WORDS 6144  // 24 KiB
 
 struct KArgs {
   const int* dc;
+  int dc_obs_words;  // prefix of the stream the observation kernel stages
   int dc_words;  // size of the device config stream; staged in LDS when it fits (MG_DC_LDS_MAX_WORDS)
   const uint16_t* map_cells;  // [P][HW]
   const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
@@ -80,6 +81,7 @@ struct KArgs {
   const float* t_gstats;      // [P][SG]
   const uint32_t* t_gtouched; // [P][GW]
   uint32_t* mt_init;          // [E][624] std::mt19937(seed) state of each env's seed
+  int env_base;               // first environment of this launch (a step may be split over concurrent streams)
   int diag;                   // diagnostic ablation bits (MG_DIAG env var): 1 = no obs stores, 2 = no scatter, 4 = no lookups
   unsigned long long* dbg;    // optional [E][16] cycle stamps (diagnostic builds of the phases; null = off)
   int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
@@ -160,7 +162,9 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take((size_t)NOBJ * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
-  size_t ai = take((size_t)(NA > 0 ? NA : 1) * 16);
+  // the static assembler info is only read while the token lists are built, the row buffers only afterwards
+  size_t ai = rows;
+  if ((size_t)(NA > 0 ? NA : 1) * 16 > (size_t)ROWB * nwaves) ai = take((size_t)(NA > 0 ? NA : 1) * 16);
   if (l) {
     l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
@@ -839,7 +843,7 @@ __device__ inline void mg_pending_uses(const KArgs& a, const Lds& l, Ctx& cx, in
 #define MG_FAST_THREADS 64
 __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   __shared__ uint32_t mtnext[624];
-  const int lane = threadIdx.x, e = blockIdx.x;
+  const int lane = threadIdx.x, e = blockIdx.x + a.env_base;
   const int A = a.A, H = a.H, W = a.W;
   const int* dc = a.dc;
   DEnv env = a.env[e];
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
 template <bool DCL>
 __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
   mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
   if (a.fast && a.mode[e] == 0) return;  // the fast kernel finished this environment's step
@@ -1233,11 +1237,11 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 template <bool DCL>
 __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x;
+  const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_words : 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
+  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
   if (DCL) {
-    for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
+    for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
     a.dc = l.dc;
   }
   MG_STAMP(0);
@@ -1408,6 +1412,9 @@ struct mg_handle {
   std::vector<void*> map_allocs;
   size_t lds_bytes = 0, lds_act = 0, lds_obs = 0;
   bool dc_lds = false;
+  int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
+  hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool maps_set = false;
   bool profiling = false;
   std::vector<hipEvent_t> ev;  // profiling ring: pairs (start, stop) per step
@@ -1492,6 +1499,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   HIPCHK(hipMemcpy(d_dc, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice));
   k.dc = d_dc;
   k.dc_words = (int)dcfg.size();
+  k.dc_obs_words = dcfg[DC_OBS_WORDS];
   size_t N = (size_t)num_envs * c.A;
   if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
@@ -1525,6 +1533,15 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &h->d_list, (size_t)num_envs * 3)) return 1;
   if (dalloc(h.get(), &h->d_inv, (size_t)2 * MGD_MAX_R)) return 1;
   HIPCHK(hipMemset(k.obs, 0xFF, N * c.T * 3));
+  {
+    const char* sp = getenv("MG_SPLIT");
+    h->n_split = sp ? std::max(1, std::min(8, atoi(sp))) : 1;
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 7; i++) {
+      HIPCHK(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+    }
+  }
   if (dalloc(h.get(), &h->masks, N)) return 1;
   HIPCHK(hipMemset(h->masks, 1, N));
   *out = h.release();
@@ -1638,8 +1655,9 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   h->lds_bytes = lds;
   h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
+  int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
   h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw, NOBJ, HEAP, NP);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP);
   if (h->lds_act > 160 * 1024 || h->lds_obs > 160 * 1024) {
     h->dc_lds = false;
     h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
@@ -1752,13 +1770,28 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
     slot = h->ev_count;
     (void)hipEventRecord(h->ev[2 * slot], s);
   }
-  if (k.fast) hipLaunchKernelGGL(mg_act_fast_kernel, dim3((unsigned)h->E), dim3(MG_FAST_THREADS), 0, s, k);
-  if (h->dc_lds) {
-    hipLaunchKernelGGL(mg_act_kernel<true>, dim3((unsigned)h->E), dim3(MG_ACT_THREADS), h->lds_act, s, k);
-    hipLaunchKernelGGL(mg_obs_kernel<true>, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_obs, s, k);
-  } else {
-    hipLaunchKernelGGL(mg_act_kernel<false>, dim3((unsigned)h->E), dim3(MG_ACT_THREADS), h->lds_act, s, k);
-    hipLaunchKernelGGL(mg_obs_kernel<false>, dim3((unsigned)h->E), dim3(MG_THREADS), h->lds_obs, s, k);
+  // The three kernels of a step are latency bound, not throughput bound: splitting the environments into groups
+  // that run on concurrent streams lets one group's observation kernel overlap another group's action kernels.
+  const int G = std::max(1, std::min(h->n_split, h->E));
+  if (G > 1) (void)hipEventRecord(h->ev_fork, s);
+  for (int gi = 0; gi < G; gi++) {
+    hipStream_t st = gi == 0 ? s : h->aux[gi - 1];
+    if (gi > 0) (void)hipStreamWaitEvent(st, h->ev_fork, 0);
+    KArgs kg = k;
+    kg.env_base = (int)((long long)h->E * gi / G);
+    const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
+    if (k.fast) hipLaunchKernelGGL(mg_act_fast_kernel, dim3(n), dim3(MG_FAST_THREADS), 0, st, kg);
+    if (h->dc_lds) {
+      hipLaunchKernelGGL(mg_act_kernel<true>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      hipLaunchKernelGGL(mg_obs_kernel<true>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    } else {
+      hipLaunchKernelGGL(mg_act_kernel<false>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      hipLaunchKernelGGL(mg_obs_kernel<false>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    }
+    if (gi > 0) {
+      (void)hipEventRecord(h->ev_join[gi - 1], st);
+      (void)hipStreamWaitEvent(s, h->ev_join[gi - 1], 0);
+    }
   }
   if (prof) {
     (void)hipEventRecord(h->ev[2 * slot + 1], s);
@@ -2026,6 +2059,11 @@ int mg_destroy(mg_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   for (void* p : h->map_allocs) (void)hipFree(p);
   for (auto& e : h->ev) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (int i = 0; i < 7; i++) {
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+  }
   delete h;
   return 0;
 }

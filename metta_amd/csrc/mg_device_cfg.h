@@ -15,6 +15,7 @@ enum MgDc {
   DC_G_COMPLETION, DC_G_LAST_ACTION, DC_G_LAST_REWARD, DC_G_COMPASS, DC_G_GOAL, DC_PROTO_OBS,
   DC_REGEN_INTERVAL, DC_INIT_PASSES, DC_N_VIBES, DC_NG, DC_N_INV_TOKENS, DC_N_ACTIONS, DC_MAX_PRIORITY,
   DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE,
+  DC_OBS_WORDS,  // the stream's prefix that the observation kernel needs (action/attack/transfer tables come after it)
   DC_FID0,
   DC_OFF_FID_INV = DC_FID0 + MG_F_COUNT, DC_OFF_FID_IN, DC_OFF_FID_OUT, DC_OFF_ACTIONS,
   DC_OFF_HANDLERS,  // 6 offsets: required/consumed kv-lists of noop, move, change_vibe
@@ -105,42 +106,6 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
   { int o = b.put_list(c.fid_inv); H(DC_OFF_FID_INV) = o + 1; }
   { int o = b.put_list(c.fid_in); H(DC_OFF_FID_IN) = o + 1; }
   { int o = b.put_list(c.fid_out); H(DC_OFF_FID_OUT) = o + 1; }
-  {
-    int o = b.reserve((int)c.actions.size() * 2);
-    for (size_t i = 0; i < c.actions.size(); i++) {
-      b.w[(size_t)o + 2 * i] = c.actions[i].kind;
-      b.w[(size_t)o + 2 * i + 1] = c.actions[i].arg;
-    }
-    H(DC_OFF_ACTIONS) = o;
-  }
-  for (int h = 0; h < MG_NUM_HANDLERS; h++) {
-    { int o = b.put_kv(c.handler[h].required); H(DC_OFF_HANDLERS + 2 * h) = o; }
-    { int o = b.put_kv(c.handler[h].consumed); H(DC_OFF_HANDLERS + 2 * h + 1) = o; }
-  }
-  { int o = b.put_list(c.vibe_handler); H(DC_OFF_VIBE_HANDLER) = o + 1; }
-  { int o = b.put_kv(c.atk_consumed); H(DC_OFF_ATK_CONSUMED) = o; }
-  { int o = b.put_kv(c.atk_defense); H(DC_OFF_ATK_DEFENSE) = o; }
-  { int o = b.put_kv(c.atk_armor); H(DC_OFF_ATK_ARMOR) = o; }
-  { int o = b.put_kv(c.atk_weapon); H(DC_OFF_ATK_WEAPON) = o; }
-  { int o = b.put_kv(c.atk_actor_delta); H(DC_OFF_ATK_ACTOR) = o; }
-  { int o = b.put_kv(c.atk_target_delta); H(DC_OFF_ATK_TARGET) = o; }
-  { int o = b.put_list(c.atk_loot); H(DC_OFF_ATK_LOOT) = o; }
-  { int o = b.put_list(c.atk_vibe_bonus); H(DC_OFF_ATK_VIBE_BONUS) = o + 1; }
-  { int o = b.put_list(c.vibe_resource); H(DC_OFF_VIBE_RESOURCE) = o + 1; }
-  { int o = b.put_kv(c.xfer_required); H(DC_OFF_XFER_REQUIRED) = o; }
-  {
-    std::vector<int32_t> rec;
-    for (const auto& e : c.xfer_effects) {
-      int oa = b.put_kv(e.actor), ot = b.put_kv(e.target);
-      rec.push_back(e.vibe);
-      rec.push_back(oa);
-      rec.push_back(ot);
-    }
-    int o = b.reserve(1 + (int)rec.size());
-    b.w[(size_t)o] = (int32_t)c.xfer_effects.size();
-    for (size_t i = 0; i < rec.size(); i++) b.w[(size_t)o + 1 + i] = rec[i];
-    H(DC_OFF_XFER_EFFECTS) = o;
-  }
   // groups
   {
     std::vector<int32_t> table;
@@ -262,6 +227,45 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
       b.w[(size_t)o + 2 * i + 1] = c.cells[i].idx;
     }
     H(DC_OFF_CELLS) = o;
+  }
+  H(DC_OBS_WORDS) = (int32_t)((b.w.size() + 3) & ~(size_t)3);
+  while (b.w.size() % 4) b.w.push_back(0);
+  // ---- tables only the action kernels read ----
+  {
+    int o = b.reserve((int)c.actions.size() * 2);
+    for (size_t i = 0; i < c.actions.size(); i++) {
+      b.w[(size_t)o + 2 * i] = c.actions[i].kind;
+      b.w[(size_t)o + 2 * i + 1] = c.actions[i].arg;
+    }
+    H(DC_OFF_ACTIONS) = o;
+  }
+  for (int h = 0; h < MG_NUM_HANDLERS; h++) {
+    { int o = b.put_kv(c.handler[h].required); H(DC_OFF_HANDLERS + 2 * h) = o; }
+    { int o = b.put_kv(c.handler[h].consumed); H(DC_OFF_HANDLERS + 2 * h + 1) = o; }
+  }
+  { int o = b.put_list(c.vibe_handler); H(DC_OFF_VIBE_HANDLER) = o + 1; }
+  { int o = b.put_kv(c.atk_consumed); H(DC_OFF_ATK_CONSUMED) = o; }
+  { int o = b.put_kv(c.atk_defense); H(DC_OFF_ATK_DEFENSE) = o; }
+  { int o = b.put_kv(c.atk_armor); H(DC_OFF_ATK_ARMOR) = o; }
+  { int o = b.put_kv(c.atk_weapon); H(DC_OFF_ATK_WEAPON) = o; }
+  { int o = b.put_kv(c.atk_actor_delta); H(DC_OFF_ATK_ACTOR) = o; }
+  { int o = b.put_kv(c.atk_target_delta); H(DC_OFF_ATK_TARGET) = o; }
+  { int o = b.put_list(c.atk_loot); H(DC_OFF_ATK_LOOT) = o; }
+  { int o = b.put_list(c.atk_vibe_bonus); H(DC_OFF_ATK_VIBE_BONUS) = o + 1; }
+  { int o = b.put_list(c.vibe_resource); H(DC_OFF_VIBE_RESOURCE) = o + 1; }
+  { int o = b.put_kv(c.xfer_required); H(DC_OFF_XFER_REQUIRED) = o; }
+  {
+    std::vector<int32_t> rec;
+    for (const auto& e : c.xfer_effects) {
+      int oa = b.put_kv(e.actor), ot = b.put_kv(e.target);
+      rec.push_back(e.vibe);
+      rec.push_back(oa);
+      rec.push_back(ot);
+    }
+    int o = b.reserve(1 + (int)rec.size());
+    b.w[(size_t)o] = (int32_t)c.xfer_effects.size();
+    for (size_t i = 0; i < rec.size(); i++) b.w[(size_t)o + 1 + i] = rec[i];
+    H(DC_OFF_XFER_EFFECTS) = o;
   }
   return b.w;
 }
