@@ -175,6 +175,28 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   return o;
 }
 
+// LDS of the assembler-use kernel (fast mode): config stream, records, stat deltas, the hand-over records.
+__host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int A, int NA, int SG, int dcw) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4), tmpo = take(8 * 96 * 4);
+  size_t ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A * 2);
+  size_t fl = take(16), rows = take((size_t)A * 32);
+  if (l) {
+    l->dc = (int*)(base + dco); l->tmp = (int*)(base + tmpo);
+    l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->gd = (int*)(base + gd);
+    l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm); l->order = (uint16_t*)(base + ord);
+    l->flags = (int*)(base + fl); l->rows = (uint8_t*)(base + rows);
+    l->grid = nullptr;
+  }
+  return o;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // cooperative pieces (all threads of the workgroup)
 // ------------------------------------------------------------------------------------------------------------
@@ -340,14 +362,18 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
 __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                      bool write_global, int tid, int nt) {
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-  uint8_t* row = l.rows + (size_t)wave * a.ROWB;
+  uint8_t* rowbuf = l.rows + (size_t)wave * a.ROWB;
   const int row_bytes = a.T * 3;
   const EncCfg ec = mg_enc_cfg(a, step);
   uint32_t pk[MG_MAX_ROUNDS];
 #pragma unroll
   for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q * 64 + lane) < ec.P ? l.pat[q * 64 + lane] : 0u;
   for (int ai = wave; ai < a.A; ai += nwaves) {
-    for (int i = lane; i < (a.ROWB >> 2); i += 64) ((uint32_t*)row)[i] = 0xFFFFFFFFu;
+    // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
+    const size_t goff = ((size_t)e * a.A + ai) * (size_t)row_bytes;
+    const int phase = (int)(goff & 15);
+    uint8_t* row = rowbuf + phase;
+    for (int i = lane; i < (a.ROWB >> 4); i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     __builtin_amdgcn_wave_barrier();
     const int act = exec ? exec[ai] : 0;
     int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, ai, act, row, pk, lane)
@@ -355,13 +381,20 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
     if (lane == 0) l.tok_att[ai] = attempted;
     __builtin_amdgcn_wave_barrier();
     if (write_global && !(a.diag & 1)) {
-      uint8_t* dst = a.obs + ((size_t)e * a.A + ai) * (size_t)row_bytes;
-      if ((row_bytes & 3) == 0) {
-        uint32_t* d32 = (uint32_t*)dst;
-        const uint32_t* s32 = (const uint32_t*)row;
-        for (int i = lane; i < (row_bytes >> 2); i += 64) d32[i] = s32[i];
-      } else {
-        for (int i = lane; i < row_bytes; i += 64) dst[i] = row[i];
+      uint8_t* gbase = a.obs + goff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
+      const int end = phase + row_bytes;
+      for (int ch = lane; ch * 16 < end; ch += 64) {
+        const int b0 = ch * 16;
+        if (b0 >= phase && b0 + 16 <= end) {
+          *(uint4*)(gbase + b0) = *(const uint4*)(rowbuf + b0);
+        } else {  // the row's ragged head / tail
+          const int lo = b0 < phase ? phase : b0, hi = b0 + 16 < end ? b0 + 16 : end;
+          if (((lo | hi) & 3) == 0) {
+            for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
+          } else {
+            for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+          }
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -588,15 +621,33 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e,
   cx.cc = CellCodec{a.NW, a.A};
 }
 
+// Cooperative copy of `bytes` (a multiple of 4) between HBM arrays: 16 bytes per lane and several loads in flight
+// when the alignment allows (restarts sit on the critical path of the act kernels).
+__device__ inline void mg_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes, int tid, int nt) {
+  if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+    const uint4* __restrict__ s = (const uint4*)src;
+    uint4* __restrict__ d = (uint4*)dst;
+    const int n = (int)(bytes >> 4);
+    int i = tid;
+    for (; i + 3 * nt < n; i += 4 * nt) {
+      uint4 v0 = s[i], v1 = s[i + nt], v2 = s[i + 2 * nt], v3 = s[i + 3 * nt];
+      d[i] = v0; d[i + nt] = v1; d[i + 2 * nt] = v2; d[i + 3 * nt] = v3;
+    }
+    for (; i < n; i += nt) d[i] = s[i];
+  } else {
+    const uint32_t* __restrict__ s = (const uint32_t*)src;
+    uint32_t* __restrict__ d = (uint32_t*)dst;
+    const int n = (int)(bytes >> 2);
+    for (int i = tid; i < n; i += nt) d[i] = s[i];
+  }
+}
+
 // Keep the finished episode's stats for the host and add it to the device-wide summary.
 __device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t steps, int tid, int nt) {
   size_t na = (size_t)a.A * a.SA, nta = (size_t)a.A * a.TW;
-  const float* as_ = a.astats + (size_t)e * na;
   float* fas = a.fin_astats + (size_t)e * na;
-  for (size_t i = tid; i < na; i += nt) fas[i] = as_[i];
-  const uint32_t* at_ = a.atouched + (size_t)e * nta;
-  uint32_t* fat = a.fin_atouched + (size_t)e * nta;
-  for (size_t i = tid; i < nta; i += nt) fat[i] = at_[i];
+  mg_copy(fas, a.astats + (size_t)e * na, na * 4, tid, nt);
+  mg_copy(a.fin_atouched + (size_t)e * nta, a.atouched + (size_t)e * nta, nta * 4, tid, nt);
   __syncthreads();
   {  // merge the record-resident counters into the finished snapshot
     const MgAgentSlots AS{a.R, a.NG};
@@ -699,35 +750,13 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
   env.mt_idx = 624;
   env.done = 0;
   env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
-  {
-    const uint4* s = (const uint4*)(a.t_agents + (size_t)m * a.A);
-    uint4* d = (uint4*)(a.agents + (size_t)e * a.A);
-    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) d[i] = s[i];
-  }
-  {
-    const uint4* s = (const uint4*)(a.t_asms + (size_t)m * a.NAmax);
-    uint4* d = (uint4*)(a.asms + (size_t)e * a.NAmax);
-    for (int i = tid; i < a.NAmax; i += nt) d[i] = s[i];
-  }
-  {
-    const float* s = a.t_astats + (size_t)m * a.A * a.SA;
-    float* d = a.astats + (size_t)e * a.A * a.SA;
-    for (int i = tid; i < a.A * a.SA; i += nt) d[i] = s[i];
-    const uint32_t* st = a.t_atouched + (size_t)m * a.A * a.TW;
-    uint32_t* dt = a.atouched + (size_t)e * a.A * a.TW;
-    for (int i = tid; i < a.A * a.TW; i += nt) dt[i] = st[i];
-    const float* sg = a.t_gstats + (size_t)m * a.SG;
-    float* dg = a.gstats + (size_t)e * a.SG;
-    for (int i = tid; i < a.SG; i += nt) dg[i] = sg[i];
-    const uint32_t* sgt = a.t_gtouched + (size_t)m * a.GW;
-    uint32_t* dgt = a.gtouched + (size_t)e * a.GW;
-    for (int i = tid; i < a.GW; i += nt) dgt[i] = sgt[i];
-  }
-  {
-    const uint32_t* s = a.mt_init + (size_t)e * 624;
-    uint32_t* d = a.mt + (size_t)e * 624;
-    for (int i = tid; i < 624; i += nt) d[i] = s[i];
-  }
+  mg_copy(a.agents + (size_t)e * a.A, a.t_agents + (size_t)m * a.A, (size_t)a.A * sizeof(DAgent), tid, nt);
+  mg_copy(a.asms + (size_t)e * a.NAmax, a.t_asms + (size_t)m * a.NAmax, (size_t)a.NAmax * sizeof(DAsm), tid, nt);
+  mg_copy(a.astats + (size_t)e * a.A * a.SA, a.t_astats + (size_t)m * a.A * a.SA, (size_t)a.A * a.SA * 4, tid, nt);
+  mg_copy(a.atouched + (size_t)e * a.A * a.TW, a.t_atouched + (size_t)m * a.A * a.TW, (size_t)a.A * a.TW * 4, tid, nt);
+  mg_copy(a.gstats + (size_t)e * a.SG, a.t_gstats + (size_t)m * a.SG, (size_t)a.SG * 4, tid, nt);
+  mg_copy(a.gtouched + (size_t)e * a.GW, a.t_gtouched + (size_t)m * a.GW, (size_t)a.GW * 4, tid, nt);
+  mg_copy(a.mt + (size_t)e * 624, a.mt_init + (size_t)e * 624, 624 * 4, tid, nt);
   for (int i = tid; i < a.A; i += nt) {
     size_t g = (size_t)e * a.A + i;
     a.rewards[g] = 0.f;
@@ -738,91 +767,6 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
   }
   __threadfence();
   __syncthreads();
-}
-
-// Assembler uses handed over by the fast act kernel, in action order, on LDS-staged agent/assembler records.
-__device__ inline void mg_pending_uses(const KArgs& a, const Lds& l, Ctx& cx, int e, const DEnv& env, int count, int tid,
-                                       int nt) {
-  const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
-  uint4* dst = (uint4*)l.ag;
-  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
-  const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
-  uint4* d2 = (uint4*)l.as;
-  for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
-  for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
-  for (int i = tid; i < a.A; i += nt) {
-    l.dirty_amt[i] = 0;
-    l.dirty_misc[i] = 0;
-  }
-  mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);  // env.step was already advanced by the fast kernel
-  cx.grid = nullptr;
-  __syncthreads();
-  MG_STAMP(9);
-  // Uses that share neither an agent nor the assembler commute, so they run on separate lanes; conflicting ones are
-  // ordered into successive rounds (round of use q = 1 + the latest round among earlier conflicting uses).
-  const uint8_t* recs = a.pend + (size_t)e * a.A * 32;
-  uint8_t* rounds = (uint8_t*)l.order;  // [A] bytes (the order array is unused on this path)
-  if (tid == 0) {
-    int max_round = 0;
-    for (int q = 0; q < count; q++) {
-      const uint8_t* rq = recs + q * 32;
-      unsigned long long mq = 0;
-      for (int i = 0; i < rq[1]; i++) mq |= 1ull << rq[8 + i];
-      int aq = rq[2] | (rq[3] << 8), rd = 0;
-      for (int p2 = 0; p2 < q; p2++) {
-        const uint8_t* rp = recs + p2 * 32;
-        unsigned long long mp = 0;
-        for (int i = 0; i < rp[1]; i++) mp |= 1ull << rp[8 + i];
-        int ap = rp[2] | (rp[3] << 8);
-        if ((mp & mq) != 0 || ap == aq) rd = max(rd, rounds[p2] + 1);
-      }
-      rounds[q] = (uint8_t)rd;
-      max_round = max(max_round, rd);
-    }
-    l.flags[0] = max_round;
-    l.flags[2] = 0;
-  }
-  __syncthreads();
-  const int max_round = l.flags[0];
-  for (int rd = 0; rd <= max_round; rd++) {
-    for (int q0 = 0; q0 < count; q0 += 8) {  // 8 scratch slots
-      int q = q0 + tid;
-      if (tid < 8 && q < count && rounds[q] == rd) {
-        const uint8_t* rec = recs + q * 32;
-        int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
-        int act = (int)(rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((uint32_t)rec[7] << 24));
-        cx.tmp = l.tmp + tid * 96;
-        int* near = cx.tmp;
-        uint8_t* vibes = (uint8_t*)(cx.tmp + 8);
-        for (int i = 0; i < 8; i++) {
-          near[i] = rec[8 + i];
-          vibes[i] = rec[16 + i];
-        }
-        bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
-        if (ok) {
-          l.ag[actor].succ[MG_ACT_MOVE] += 1;
-          a.exec[(size_t)e * a.A + actor] = act;
-          a.success[(size_t)e * a.A + actor] = 1;
-        } else {
-          l.ag[actor].fail[MG_ACT_MOVE] += 1;
-        }
-        if (cx.asm_dirty) l.flags[2] = 1;
-      }
-      __syncthreads();
-    }
-  }
-  __syncthreads();
-  MG_STAMP(10);
-  mg_flush_stats(a, l, cx, e, tid, nt);
-  uint4* wd = (uint4*)(a.agents + (size_t)e * a.A);
-  const uint4* ws = (const uint4*)l.ag;
-  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) wd[i] = ws[i];
-  if (l.flags[2]) {
-    uint4* wd2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
-    const uint4* ws2 = (const uint4*)l.as;
-    for (int i = tid; i < a.NAmax; i += nt) wd2[i] = ws2[i];
-  }
-  MG_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -865,14 +809,8 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   int r = (int)(f0.x & 0xFFFF), c = (int)(f0.x >> 16);
   int frozen = (int)(int16_t)(f0.z & 0xFFFF);
   uint32_t vibe = (f0.z >> 16) & 0xFF, group = f0.z >> 24, swm = f0.w;
-  const bool any_frozen = __ballot(active && frozen != 0) != 0;
-  if (any_frozen) {  // wave-uniform; cannot arise in eligible configurations, kept as a guard
-    if (lane == 0) {
-      a.env[e] = env;
-      a.mode[e] = 2;
-    }
-    return;
-  }
+  // Eligible configurations have no attacks, so nothing can freeze an agent; flag it loudly if it ever happens.
+  if (__ballot(active && frozen != 0) != 0) env.error |= 4u;
 
   // ---- MT19937 window -------------------------------------------------------------------
   const uint32_t* mt = a.mt + (size_t)e * 624;
@@ -911,24 +849,53 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
     reject = low < range && low < (0u - range) % range;  // Lemire rejection: extremely rare, needs a serial redraw
     val = (uint32_t)(product >> 32);
   }
-  if (__ballot(reject) != 0) {
-    if (lane == 0) {
-      a.env[e] = env;  // keep a restart done above
-      a.mode[e] = 2;
+  uint32_t used = (uint32_t)D;  // MT19937 outputs consumed by the shuffle
+  if (__ballot(reject) != 0 || (a.diag & 8)) {
+    // A rejected draw shifts every later draw by one output: redo the draws one after the other (wave-uniform scalars;
+    // about one step in a million takes this branch, MG_DIAG bit 8 forces it for the tests).
+    int idx = 0;
+    bool overflow = false;
+    for (int t = 0; t < D; t++) {
+      uint32_t range = 2;
+      if (!(even && t == 0)) {
+        const uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (t - even));
+        range = (i + 1) * (i + 2);
+      }
+      const uint32_t threshold = (0u - range) % range;
+      uint32_t hi = 0;
+      for (;;) {
+        if (idx >= NW_) {
+          overflow = true;
+          break;
+        }
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, idx);
+        idx++;
+        const unsigned long long product = (unsigned long long)wv * range;
+        const uint32_t low = (uint32_t)product;
+        hi = (uint32_t)(product >> 32);
+        if (!(low < range && low < threshold)) break;
+      }
+      if (lane == t) val = hi;
     }
-    return;
+    used = (uint32_t)idx;
+    if (overflow) env.error |= 1u;
   }
-  // ranks: agent x sits at position rank_x of the shuffled order; a swap of positions (p, q) exchanges the ranks
+  // ranks: agent x sits at position rank_x of the shuffled order; a swap of positions (p, q) exchanges the ranks.
+  // The two swap partners of draw t (x / (s+1), x % (s+1)) are derived once, lane-parallel.
+  int pa_l = 0, pb_l = 0;
+  if (lane < D && !(even && lane == 0)) {
+    const uint32_t s1 = (uint32_t)((even ? 2 : 1) + 2 * (lane - even)) + 2u;  // s + 1
+    pa_l = (int)(val / s1);
+    pb_l = (int)(val - (uint32_t)pa_l * s1);
+  }
   int rank = lane;
   for (int t = 0; t < D; t++) {
-    uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)val, t);
     if (even && t == 0) {
-      int j = (int)x;  // swap(v[1], v[j])
+      int j = __builtin_amdgcn_readlane((int)val, 0);  // swap(v[1], v[j])
       rank = rank == 1 ? j : (rank == j ? 1 : rank);
     } else {
       int i = (even ? 2 : 1) + 2 * (t - even);
-      int s = i + 1;
-      int pa = (int)(x / (uint32_t)(s + 1)), pb = (int)(x % (uint32_t)(s + 1));
+      int pa = __builtin_amdgcn_readlane(pa_l, t), pb = __builtin_amdgcn_readlane(pb_l, t);
       rank = rank == i ? pa : (rank == pa ? i : rank);
       rank = rank == i + 1 ? pb : (rank == pb ? i + 1 : rank);
     }
@@ -964,21 +931,23 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   const uint32_t Tm = mover ? (((uint32_t)tr << 16) | (uint32_t)tc) : 0xFFFFFFFFu;
 
   // ---- fixed point over move success ----------------------------------------------------------------------
+  // Per lane, once: who stands on my target, who else wants it, who acts before me.  Each iteration is then a
+  // handful of mask operations on the ballot of the current guess.
+  unsigned long long occ = 0, tgt = 0, lower = 0;
+  for (int j = 0; j < A; j++) {
+    const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
+    const uint32_t Tj = (uint32_t)__builtin_amdgcn_readlane((int)Tm, j);
+    const int rj = __builtin_amdgcn_readlane(rank, j);
+    const unsigned long long bit = 1ull << j;
+    if (Pj == Tm) occ |= bit;
+    if (Tj == Tm && j != lane) tgt |= bit;
+    if (rj < rank) lower |= bit;
+  }
   bool m = mover;
   for (int it = 0; it <= A; it++) {
-    unsigned long long mm = __ballot(m);
-    bool blocked = false;
-    for (int j = 0; j < A; j++) {
-      uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
-      uint32_t Tj = (uint32_t)__builtin_amdgcn_readlane((int)Tm, j);
-      int rj = __builtin_amdgcn_readlane(rank, j);
-      bool mj = (mm >> j) & 1ull;
-      bool left_before = rj < rank && mj;          // j moved away before my turn
-      bool came_before = rj < rank && mj;          // j moved in before my turn
-      if (j != lane) blocked |= (Pj == Tm && !left_before) || (Tj == Tm && came_before);
-    }
-    bool nm = mover && !blocked;
-    bool changed = nm != m;
+    const unsigned long long before = lower & __ballot(m);  // moved (away / in) before my turn
+    const bool nm = mover && (occ & ~before) == 0 && (tgt & before) == 0;
+    const bool changed = nm != m;
     m = nm;
     if (__ballot(changed) == 0) break;
   }
@@ -1092,7 +1061,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
     a.success[g] = ok ? 1 : 0;
   }
   // ---- env write-back ------------------------------------------------------------------------------------------
-  uint32_t new_idx = env.mt_idx + (uint32_t)D;
+  uint32_t new_idx = env.mt_idx + used;
   if (new_idx > 624) {
     uint32_t* mtw = a.mt + (size_t)e * 624;
     for (int i = lane; i < 624; i += 64) mtw[i] = mtnext[i];
@@ -1107,6 +1076,120 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// kernel 1b (fast path): assembler uses handed over by mg_act_fast_kernel, in action order, on LDS-staged
+// agent/assembler records.  One wave per environment; environments without uses leave at once.  The LDS
+// footprint is kept small (no map tile, no RNG window) so that every environment with work is resident at once:
+// the kernel's duration is the latency of one environment's chain, not a sum of rounds.
+// ------------------------------------------------------------------------------------------------------------
+#define MG_USES_THREADS 64
+template <bool DCL>
+__global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, nt = MG_USES_THREADS, e = blockIdx.x + a.env_base;
+  const uint32_t mode = a.mode[e];
+  if ((mode & 0xFF) != 1) return;
+  const int count = (int)(mode >> 8);
+  Lds l;
+  mg_carve_uses(smem, &l, a.A, a.NAmax, a.SG, DCL ? a.dc_words : 0);
+  MG_STAMP(8);
+  // every staging load is independent of the others: issue them together, one barrier
+  const uint32_t step = a.env[e].step;  // already advanced by the fast kernel
+  const uint32_t map_id = a.env[e].map_id;
+  {
+    const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
+    uint4* d1 = (uint4*)l.ag;
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) d1[i] = s1[i];
+    const uint4* __restrict__ s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
+    uint4* d2 = (uint4*)l.as;
+    for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
+    const uint4* __restrict__ s3 = (const uint4*)(a.pend + (size_t)e * a.A * 32);
+    uint4* d3 = (uint4*)l.rows;
+    for (int i = tid; i < count * 2; i += nt) d3[i] = s3[i];
+    if (DCL) {
+      const uint4* __restrict__ s0 = (const uint4*)a.dc;
+      uint4* d0 = (uint4*)l.dc;
+      for (int i = tid; i < (a.dc_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
+    }
+    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+    for (int i = tid; i < a.A; i += nt) {
+      l.dirty_amt[i] = 0;
+      l.dirty_misc[i] = 0;
+    }
+  }
+  if (DCL) a.dc = l.dc;
+  Ctx cx;
+  mg_make_ctx(a, l, cx, e, (int)map_id, step);
+  cx.grid = nullptr;
+  __syncthreads();
+  MG_STAMP(9);
+  // Uses that share neither an agent nor the assembler commute, so they run on separate lanes; conflicting ones are
+  // ordered into successive rounds (round of use q = 1 + the latest round among earlier conflicting uses).
+  const uint8_t* recs = l.rows;
+  uint8_t* rounds = (uint8_t*)l.order;  // [A] bytes
+  if (tid == 0) {
+    int max_round = 0;
+    for (int q = 0; q < count; q++) {
+      const uint8_t* rq = recs + q * 32;
+      unsigned long long mq = 0;
+      for (int i = 0; i < rq[1]; i++) mq |= 1ull << rq[8 + i];
+      int aq = rq[2] | (rq[3] << 8), rd = 0;
+      for (int p2 = 0; p2 < q; p2++) {
+        const uint8_t* rp = recs + p2 * 32;
+        unsigned long long mp = 0;
+        for (int i = 0; i < rp[1]; i++) mp |= 1ull << rp[8 + i];
+        int ap = rp[2] | (rp[3] << 8);
+        if ((mp & mq) != 0 || ap == aq) rd = max(rd, rounds[p2] + 1);
+      }
+      rounds[q] = (uint8_t)rd;
+      max_round = max(max_round, rd);
+    }
+    l.flags[0] = max_round;
+    l.flags[2] = 0;
+  }
+  __syncthreads();
+  const int max_round = l.flags[0];
+  for (int rd = 0; rd <= max_round; rd++) {
+    for (int q0 = 0; q0 < count; q0 += 8) {  // 8 scratch slots
+      int q = q0 + tid;
+      if (tid < 8 && q < count && rounds[q] == rd) {
+        const uint8_t* rec = recs + q * 32;
+        int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
+        int act = (int)(rec[4] | (rec[5] << 8) | (rec[6] << 16) | ((uint32_t)rec[7] << 24));
+        cx.tmp = l.tmp + tid * 96;
+        int* near = cx.tmp;
+        uint8_t* vibes = (uint8_t*)(cx.tmp + 8);
+        for (int i = 0; i < 8; i++) {
+          near[i] = rec[8 + i];
+          vibes[i] = rec[16 + i];
+        }
+        bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
+        if (ok) {
+          l.ag[actor].succ[MG_ACT_MOVE] += 1;
+          a.exec[(size_t)e * a.A + actor] = act;
+          a.success[(size_t)e * a.A + actor] = 1;
+        } else {
+          l.ag[actor].fail[MG_ACT_MOVE] += 1;
+        }
+        if (cx.asm_dirty) l.flags[2] = 1;
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  MG_STAMP(10);
+  mg_flush_stats(a, l, cx, e, tid, nt);
+  uint4* wd = (uint4*)(a.agents + (size_t)e * a.A);
+  const uint4* ws = (const uint4*)l.ag;
+  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) wd[i] = ws[i];
+  if (l.flags[2]) {
+    uint4* wd2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
+    const uint4* ws2 = (const uint4*)l.as;
+    for (int i = tid; i < a.NAmax; i += nt) wd2[i] = ws2[i];
+  }
+  MG_STAMP(11);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // kernel 1: actions.  One wave per environment; thread 0 resolves the actions in the reference's shuffled
 // sequential order on LDS state (bindings/mettagrid_c.cpp:572-650).
 // ------------------------------------------------------------------------------------------------------------
@@ -1117,7 +1200,6 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
   mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
-  if (a.fast && a.mode[e] == 0) return;  // the fast kernel finished this environment's step
   MG_STAMP(8);
   if (DCL) {
     for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
@@ -1127,16 +1209,6 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   DEnv env = a.env[e];
   const int* dc = a.dc;
   Ctx cx;
-
-  if (a.fast) {
-    // Hand-off from mg_act_fast_kernel: nothing left, only assembler uses left, or the whole step.
-    uint32_t mode = a.mode[e];
-    if (mode == 0) return;
-    if ((mode & 0xFF) == 1) {
-      mg_pending_uses(a, l, cx, e, env, (int)(mode >> 8), tid, nt);
-      return;
-    }
-  }
 
   const bool do_reset = a.auto_reset && env.done;  // block-uniform
   if (do_reset) mg_restart_env(a, e, env, tid, nt);
@@ -1410,7 +1482,7 @@ struct mg_handle {
   KArgs k;
   std::vector<void*> allocs;
   std::vector<void*> map_allocs;
-  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0;
+  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0;
   bool dc_lds = false;
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1479,7 +1551,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   k.TW = (k.SA + 31) / 32; k.GW = (k.SG + 31) / 32; k.n_cells = (int)c.cells.size();
   k.NWIN = std::min(624, c.A / 2 + 2 + MG_WIN_MARGIN);
   if (c.A / 2 + 2 > 624) return fail("mg_create: too many agents for the RNG window");
-  k.ROWB = (int)mg_align16((size_t)c.T * 3);
+  k.ROWB = (int)mg_align16((size_t)c.T * 3) + 16;  // + the row's 16-byte phase in HBM (mg_encode_all)
   k.auto_reset = 1; k.map_stride = 1;
   {
     // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
@@ -1663,11 +1735,14 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
     h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
     h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
   }
+  h->lds_uses = mg_carve_uses(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
   if (h->dc_lds) {
     HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_uses));
     HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
   } else {
     HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_uses));
     HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
   }
   HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1780,14 +1855,16 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
     KArgs kg = k;
     kg.env_base = (int)((long long)h->E * gi / G);
     const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
-    if (k.fast) hipLaunchKernelGGL(mg_act_fast_kernel, dim3(n), dim3(MG_FAST_THREADS), 0, st, kg);
-    if (h->dc_lds) {
-      hipLaunchKernelGGL(mg_act_kernel<true>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
-      hipLaunchKernelGGL(mg_obs_kernel<true>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    if (k.fast) {
+      hipLaunchKernelGGL(mg_act_fast_kernel, dim3(n), dim3(MG_FAST_THREADS), 0, st, kg);
+      if (h->dc_lds) hipLaunchKernelGGL(mg_uses_kernel<true>, dim3(n), dim3(MG_USES_THREADS), h->lds_uses, st, kg);
+      else hipLaunchKernelGGL(mg_uses_kernel<false>, dim3(n), dim3(MG_USES_THREADS), h->lds_uses, st, kg);
     } else {
-      hipLaunchKernelGGL(mg_act_kernel<false>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
-      hipLaunchKernelGGL(mg_obs_kernel<false>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+      if (h->dc_lds) hipLaunchKernelGGL(mg_act_kernel<true>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      else hipLaunchKernelGGL(mg_act_kernel<false>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
     }
+    if (h->dc_lds) hipLaunchKernelGGL(mg_obs_kernel<true>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    else hipLaunchKernelGGL(mg_obs_kernel<false>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
     if (gi > 0) {
       (void)hipEventRecord(h->ev_join[gi - 1], st);
       (void)hipStreamWaitEvent(s, h->ev_join[gi - 1], 0);

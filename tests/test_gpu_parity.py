@@ -62,7 +62,17 @@ def _compare_state(b, oras, t):
         assert b.current_step(e) == o.current_step
 
 
-def test_arena_vs_oracle():
+@pytest.mark.parametrize(
+    "path_env",
+    [{}, {"MG_DIAG": "8"}, {"MG_FORCE_GENERAL": "1"}],
+    ids=["fast", "fast-serial-redraw", "general"],
+)
+def test_arena_vs_oracle(path_env, monkeypatch):
+    """The same comparison through each act-kernel path: the wave-parallel fast kernel (+ the assembler-use
+    kernel), its serial shuffle redraw (taken on a Lemire rejection, about once in 1e6 env-steps; MG_DIAG bit 8
+    forces it), and the general sequential kernel.  The variables are read by mg_create."""
+    for k, v in path_env.items():
+        monkeypatch.setenv(k, v)
     cfg = make_arena(24)
     maps = load_map_pool()[:6]
     E, A = 12, 24
