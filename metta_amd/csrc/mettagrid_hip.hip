@@ -82,7 +82,7 @@ struct KArgs {
   const uint32_t* t_gtouched; // [P][GW]
   uint32_t* mt_init;          // [E][624] std::mt19937(seed) state of each env's seed
   int env_base;               // first environment of this launch (a step may be split over concurrent streams)
-  int diag;                   // diagnostic ablation bits (MG_DIAG env var): 1 = no obs stores, 2 = no scatter, 4 = no lookups
+  int diag;                   // diagnostic ablation bits (MG_DIAG env var): 1 = no obs stores, 8 = serial shuffle redraw, 16 / 32 / 64 = skip encode / token lists / rewards in the obs kernel
   unsigned long long* dbg;    // optional [E][16] cycle stamps (diagnostic builds of the phases; null = off)
   int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
   int auto_reset, map_stride;
@@ -368,37 +368,53 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   uint32_t pk[MG_MAX_ROUNDS];
 #pragma unroll
   for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q * 64 + lane) < ec.P ? l.pat[q * 64 + lane] : 0u;
-  for (int ai = wave; ai < a.A; ai += nwaves) {
-    // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
-    const size_t goff = ((size_t)e * a.A + ai) * (size_t)row_bytes;
-    const int phase = (int)(goff & 15);
-    uint8_t* row = rowbuf + phase;
-    for (int i = lane; i < (a.ROWB >> 4); i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    __builtin_amdgcn_wave_barrier();
-    const int act = exec ? exec[ai] : 0;
-    int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, ai, act, row, pk, lane)
-                                : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, ai, act, row, pk, lane);
-    if (lane == 0) l.tok_att[ai] = attempted;
-    __builtin_amdgcn_wave_barrier();
-    if (write_global && !(a.diag & 1)) {
-      uint8_t* gbase = a.obs + goff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
-      const int end = phase + row_bytes;
-      for (int ch = lane; ch * 16 < end; ch += 64) {
-        const int b0 = ch * 16;
-        if (b0 >= phase && b0 + 16 <= end) {
-          *(uint4*)(gbase + b0) = *(const uint4*)(rowbuf + b0);
-        } else {  // the row's ragged head / tail
-          const int lo = b0 < phase ? phase : b0, hi = b0 + 16 < end ? b0 + 16 : end;
-          if (((lo | hi) & 3) == 0) {
-            for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
-          } else {
-            for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+  // Rows whose length is 8 mod 16 (T = 200: 600 bytes) alternate between phase 0 and 8 in HBM.  A wave then takes
+  // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
+  // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
+  // more than the whole rest of the row).
+  const bool pairs = write_global && (a.A & 1) == 0 && (row_bytes & 15) == 8;
+  const int group = pairs ? 2 : 1;
+  uint2 carry = make_uint2(0, 0);
+  for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group)
+    for (int h = 0; h < group; h++) {
+      const int ai = a0 + h;
+      // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
+      const size_t goff = ((size_t)e * a.A + ai) * (size_t)row_bytes;
+      const int phase = (int)(goff & 15);
+      uint8_t* row = rowbuf + phase;
+      for (int i = lane; i < (a.ROWB >> 4); i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
+      __builtin_amdgcn_wave_barrier();
+      const int act = exec ? exec[ai] : 0;
+      int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, ai, act, row, pk, lane)
+                                  : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, ai, act, row, pk, lane);
+      if (lane == 0) l.tok_att[ai] = attempted;
+      __builtin_amdgcn_wave_barrier();
+      if (write_global && !(a.diag & 1)) {
+        uint8_t* gbase = a.obs + goff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
+        const int end = phase + row_bytes;
+        const int first = pairs ? 0 : phase;            // pairs, odd row: the chunk at 0 holds the even row's tail
+        const int last = pairs && h == 0 ? end - 8 : end;  // pairs, even row: the tail waits for the odd row
+        if (pairs && h == 0) carry = *(const uint2*)(rowbuf + end - 8);
+        for (int ch = lane; ch * 16 < last; ch += 64) {
+          const int b0 = ch * 16;
+          if (b0 >= first && b0 + 16 <= last) {
+            // streamed out, never re-read by the step kernels: keep it from displacing the map pool and records in L2
+            const uint4 v = *(const uint4*)(rowbuf + b0);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + b0));
+          } else {  // the row's ragged head / tail
+            const int lo = b0 < first ? first : b0, hi = b0 + 16 < last ? b0 + 16 : last;
+            if (((lo | hi) & 3) == 0) {
+              for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
+            } else {
+              for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+            }
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-  }
 }
 
 // Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
@@ -1336,12 +1352,13 @@ __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   mg_overlay_agents(a, l, tid, nt);
   __syncthreads();
   MG_STAMP(2);
-  mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);
+  if (!(a.diag & 32)) mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);
   __syncthreads();
   MG_STAMP(3);
-  mg_encode_all(a, l, e, env.step, l.exec, true, tid, nt);
+  if (!(a.diag & 16)) mg_encode_all(a, l, e, env.step, l.exec, true, tid, nt);
   __syncthreads();
   MG_STAMP(4);
+  if (a.diag & 64) return;
   if (tid == 0) {
     mg_token_stats(a, l, 1);
     float* gs_ = a.gstats + (size_t)e * a.SG;
