@@ -248,25 +248,50 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
 struct EncCfg {  // per-kernel constants of the encoder, read from the config stream once (not per agent)
   int oh, ow, hr, wr, P, T, H, W;
   uint32_t center;
-  int g_completion, g_last_action, g_last_reward, g_goal, g_compass;
-  uint32_t f_completion, f_last_action, f_last_reward, f_goal, f_compass;
-  int pct;
+  int g_goal, g_compass;
+  uint32_t f_goal, f_compass;
 };
-__device__ inline EncCfg mg_enc_cfg(const KArgs& a, uint32_t step) {
+__device__ inline EncCfg mg_enc_cfg(const KArgs& a) {
   const int* dc = a.dc;
   EncCfg c;
   c.oh = dc[DC_OBS_H]; c.ow = dc[DC_OBS_W]; c.hr = c.oh >> 1; c.wr = c.ow >> 1; c.P = dc[DC_PATTERN_N]; c.T = a.T;
   c.H = a.H; c.W = a.W;
   c.center = (uint32_t)((c.hr << 4) | (c.wr & 0x0F));
-  c.g_completion = dc[DC_G_COMPLETION]; c.g_last_action = dc[DC_G_LAST_ACTION]; c.g_last_reward = dc[DC_G_LAST_REWARD];
   c.g_goal = dc[DC_G_GOAL]; c.g_compass = dc[DC_G_COMPASS];
-  c.f_completion = (uint32_t)dc[DC_FID0 + MG_F_COMPLETION]; c.f_last_action = (uint32_t)dc[DC_FID0 + MG_F_LAST_ACTION];
-  c.f_last_reward = (uint32_t)dc[DC_FID0 + MG_F_LAST_REWARD]; c.f_goal = (uint32_t)dc[DC_FID0 + MG_F_GOAL];
+  c.f_goal = (uint32_t)dc[DC_FID0 + MG_F_GOAL];
   c.f_compass = (uint32_t)dc[DC_FID0 + MG_F_COMPASS];
-  int ms = dc[DC_MAX_STEPS];
-  c.pct = 0;
-  if (ms > 0) c.pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
   return c;
+}
+// The fixed global tokens, one per lane (lane i < n holds the i-th): episode_completion_pct, last_action,
+// last_reward in the reference's order (bindings/mettagrid_c.cpp:416-447).
+struct GlobalTok {
+  int n;
+  uint32_t f, v;
+  bool is_action;
+};
+__device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lane) {
+  const int* dc = a.dc;
+  GlobalTok g;
+  g.f = 0; g.v = 0; g.is_action = false;
+  int n = 0;
+  if (dc[DC_G_COMPLETION]) {
+    const int ms = dc[DC_MAX_STEPS];
+    int pct = 0;
+    if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_COMPLETION]; g.v = (uint32_t)pct; }
+    n++;
+  }
+  if (dc[DC_G_LAST_ACTION]) {
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_LAST_ACTION]; g.is_action = true; }
+    n++;
+  }
+  if (dc[DC_G_LAST_REWARD]) {
+    // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_LAST_REWARD]; g.v = 0; }
+    n++;
+  }
+  g.n = n;
+  return g;
 }
 
 #define MG_MAX_ROUNDS 4  // ceil(15 * 15 / 64): observation windows are at most 15 x 15
@@ -274,8 +299,8 @@ __device__ inline EncCfg mg_enc_cfg(const KArgs& a, uint32_t step) {
 // One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
 // MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
 template <int NR>
-__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, int ai, int action,
-                                      uint8_t* __restrict__ row, const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
+__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt, int ai,
+                                      int action, uint8_t* __restrict__ row, const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
   const DAgent* me = &l.ag[ai];
   const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
   const int ar = me->r, ac = me->c;
@@ -287,13 +312,20 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
     meta[q] = 0;
     int p = q * 64 + lane;
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
-    if (p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W) {
+    if (p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && !(a.diag & 512)) {
       uint16_t cv = l.grid[r * W + c];
       if (cv != 0) meta[q] = l.ocnt[(int)cv - 1];  // heap offset | token count << 16
     }
   }
-  int base = 0;
-  if (lane == 0) {  // global tokens + compass at/around the centre (a handful; one lane)
+  // Global tokens at the centre.  The fixed ones (episode completion, last action, last reward) sit one per lane,
+  // prepared once per wave (GlobalTok); goal and compass tokens depend on the agent and follow from lane 0.
+  int base = gt.n;
+  if (lane < gt.n && lane < T) {
+    row[lane * 3 + 0] = (uint8_t)ec.center;
+    row[lane * 3 + 1] = (uint8_t)gt.f;
+    row[lane * 3 + 2] = (uint8_t)(gt.is_action ? action : gt.v);
+  }
+  if ((ec.g_goal || ec.g_compass) && lane == 0) {
     const uint8_t loc = (uint8_t)ec.center;
     auto put = [&](uint8_t lc, uint32_t f, int v) {
       if (base < T) {
@@ -303,10 +335,6 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
       }
       base++;
     };
-    if (ec.g_completion) put(loc, ec.f_completion, ec.pct);
-    if (ec.g_last_action) put(loc, ec.f_last_action, action);
-    // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
-    if (ec.g_last_reward) put(loc, ec.f_last_reward, 0);
     if (ec.g_goal) {
       const int* dc = a.dc;
       int og = group_rec(dc, me->group)[GR_OFF_GOAL], ng = L_n(dc, og);
@@ -337,7 +365,7 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
       if (lane > j) off += cj;
     }
     off += base;
-    if (cnt > 0 && off < T) {
+    if (cnt > 0 && off < T && !(a.diag & 128)) {
       // token lists start 8-byte aligned and are padded to x4 tokens: read 4 tokens per LDS access
       const uint2* __restrict__ src = (const uint2*)(l.heap + (meta[q] & 0xFFFF));
       const uint8_t loc = (uint8_t)(pk[q] >> 16);
@@ -364,7 +392,8 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
   uint8_t* rowbuf = l.rows + (size_t)wave * a.ROWB;
   const int row_bytes = a.T * 3;
-  const EncCfg ec = mg_enc_cfg(a, step);
+  const EncCfg ec = mg_enc_cfg(a);
+  const GlobalTok gt = mg_global_tok(a, step, lane);
   uint32_t pk[MG_MAX_ROUNDS];
 #pragma unroll
   for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q * 64 + lane) < ec.P ? l.pat[q * 64 + lane] : 0u;
@@ -386,8 +415,8 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
-      int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, ai, act, row, pk, lane)
-                                  : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, ai, act, row, pk, lane);
+      int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, gt, ai, act, row, pk, lane)
+                                  : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, gt, ai, act, row, pk, lane);
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {
