@@ -36,6 +36,7 @@ sys.path.insert(0, str(ROOT))
 ENVS_PER_GPU = 4096
 AGENTS = 24
 ALGO_BYTES_PER_AGENT_STEP = 1035.0  # 610 B boundary + ~425 B state (arena)
+OBS_BYTES_PER_AGENT_STEP = 970.0  # the observation kernel alone, 600 B written + ~370 B read
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 
 
@@ -190,6 +191,13 @@ def main() -> None:
     dt = time.perf_counter() - t0
     kernel_ms = batch.profile_read(4096)
     batch.set_profiling(False)
+    # after the timed region: a short pass with events around the observation kernel alone (SURVEY 8d metric 2)
+    batch.set_profiling(2)
+    n_obs = min(args.steps, 100)
+    run(n_obs, args.warmup + args.steps)
+    sync_all()
+    obs_ms = batch.profile_read(4096)
+    batch.set_profiling(False)
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -238,10 +246,18 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "mg_step_kernel",
+                "kernel": "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel (the three launches of one step)",
                 "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
                 "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "obs_kernel": {
+                    "ms_mean": float(obs_ms.mean()) if len(obs_ms) else None,
+                    "algorithmic_bytes_per_launch": OBS_BYTES_PER_AGENT_STEP * E * A,
+                    "achieved": OBS_BYTES_PER_AGENT_STEP * E * A / (float(obs_ms.mean()) * 1e-3) / 1e9 if len(obs_ms) else None,
+                    "frac": OBS_BYTES_PER_AGENT_STEP * E * A / (float(obs_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    if len(obs_ms)
+                    else None,
+                },
             },
             "cpu_baseline": cpu,
         }

@@ -120,7 +120,8 @@ int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream);
 
 /* Per-step kernel timing with HIP events recorded on the stream each step kernel is launched on (no host sync in
  * the step call).  mg_set_profiling(h, 1) starts recording (up to 4096 steps); mg_profile_read waits for the
- * recorded steps, writes their durations in milliseconds and restarts recording.  bench.py's roofline line. */
+ * recorded steps, writes their durations in milliseconds and restarts recording.  bench.py's roofline line.
+ * mg_set_profiling(h, 2) brackets the observation kernel only (SURVEY.md §8d metric 2: obs-encode GB/s). */
 int mg_set_profiling(mg_handle* h, int enabled);
 int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps);
 

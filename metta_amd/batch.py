@@ -153,7 +153,8 @@ class MettaGridBatch:
     def end_episode(self, env: int = -1) -> None:
         native.check(self.L.mg_end_episode(self._h, int(env), self._stream()))
 
-    def set_profiling(self, enabled: bool) -> None:
+    def set_profiling(self, enabled) -> None:
+        """False/0 off, True/1 time whole steps, 2 time the observation kernel only (HIP events on the launch stream)."""
         native.check(self.L.mg_set_profiling(self._h, int(enabled)))
 
     def profile_read(self, max_steps: int = 4096) -> np.ndarray:

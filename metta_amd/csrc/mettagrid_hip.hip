@@ -1534,7 +1534,7 @@ struct mg_handle {
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool maps_set = false;
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 whole step, 2 observation kernel only
   std::vector<hipEvent_t> ev;  // profiling ring: pairs (start, stop) per step
   size_t ev_count = 0;         // steps recorded since profiling was enabled
   std::vector<std::vector<int4>> host_spawn, host_asm;  // per map (inspection)
@@ -1887,9 +1887,10 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
   if (actions) k.actions = actions;
   size_t slot = 0;
   bool prof = h->profiling && h->ev_count < MG_PROFILE_RING;
+  const bool obs_only = prof && h->profiling == 2 && h->n_split <= 1;
   if (prof) {
     slot = h->ev_count;
-    (void)hipEventRecord(h->ev[2 * slot], s);
+    if (!obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
   }
   // The three kernels of a step are latency bound, not throughput bound: splitting the environments into groups
   // that run on concurrent streams lets one group's observation kernel overlap another group's action kernels.
@@ -1909,6 +1910,7 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
       if (h->dc_lds) hipLaunchKernelGGL(mg_act_kernel<true>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
       else hipLaunchKernelGGL(mg_act_kernel<false>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
     }
+    if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
     if (h->dc_lds) hipLaunchKernelGGL(mg_obs_kernel<true>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
     else hipLaunchKernelGGL(mg_obs_kernel<false>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
     if (gi > 0) {
@@ -2126,7 +2128,7 @@ int mg_set_profiling(mg_handle* h, int enabled) {
     h->ev.resize(2 * MG_PROFILE_RING);
     for (auto& e : h->ev) HIPCHK(hipEventCreate(&e));
   }
-  h->profiling = enabled != 0;
+  h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
   h->ev_count = 0;
   return 0;
 }
