@@ -52,6 +52,15 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
  * must hold exactly num_agents agent cells.  Object ids / agent ids follow row-major creation order. */
 int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int width);
 
+/* As mg_set_maps for a pool whose maps differ in size (the navigation suite, SURVEY.md §8d config 3: the reference
+ * builds one `MettaGrid` per map, each with its own `map_height/map_width`): `maps` holds the P maps back to back,
+ * map m being heights[m] x widths[m] row-major.  Everything that depends on the map size (bounds, the compass
+ * token's map centre, mettagrid_c.cpp:483-517) uses the size of the map an environment currently plays. */
+int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths);
+
+/* `MettaGrid.map_height / map_width` (mettagrid_c.cpp:1040-1041) of map `map_id` of the pool. */
+int mg_map_dims(mg_handle* h, int map_id, int32_t* height, int32_t* width);
+
 /* (Re)start environments: env_ids[n] (NULL = all E, then n is ignored), each with seeds[i] (std::mt19937 seed of
  * the env, mettagrid_c.cpp:56-57) and map_ids[i] (index into the pool).  Computes the step-0 observations exactly
  * like `_init_buffers` (mettagrid_c.cpp:264-289).  Host arrays. */

@@ -93,13 +93,29 @@ class MettaGridBatch:
         for m in maps:
             arr = np.asarray(m)
             enc.append(arr.astype(np.uint8) if arr.dtype.kind in "ui" else self.compiled.encode_map(arr))
-        shapes = {e.shape for e in enc}
-        if len(shapes) != 1:
-            raise RuntimeError("all maps of a batch must share one (height, width)")
-        pool = np.ascontiguousarray(np.stack(enc), dtype=np.uint8)
-        self.map_pool = pool
-        self.map_height, self.map_width = pool.shape[1], pool.shape[2]
-        native.check(self.L.mg_set_maps(self._h, _p(pool, ct.c_uint8), pool.shape[0], pool.shape[1], pool.shape[2]))
+        enc = [np.ascontiguousarray(e, dtype=np.uint8) for e in enc]
+        if any(e.ndim != 2 for e in enc):
+            raise RuntimeError("maps must be 2-D")
+        self.map_pool = enc
+        self.map_dims = np.array([e.shape for e in enc], dtype=np.int32)  # [P][2] = (height, width)
+        # the reference's read-only map_height / map_width; for a mixed pool: the largest (see map_dims, env_map_dims)
+        self.map_height, self.map_width = int(self.map_dims[:, 0].max()), int(self.map_dims[:, 1].max())
+        if len({e.shape for e in enc}) == 1:
+            pool = np.ascontiguousarray(np.stack(enc), dtype=np.uint8)
+            native.check(self.L.mg_set_maps(self._h, _p(pool, ct.c_uint8), pool.shape[0], pool.shape[1], pool.shape[2]))
+        else:  # maps of different sizes (navigation suite): back to back, with their dimensions
+            flat = np.ascontiguousarray(np.concatenate([e.reshape(-1) for e in enc]), dtype=np.uint8)
+            hs = np.ascontiguousarray(self.map_dims[:, 0])
+            ws = np.ascontiguousarray(self.map_dims[:, 1])
+            native.check(
+                self.L.mg_set_maps_ragged(self._h, _p(flat, ct.c_uint8), len(enc), _p(hs, ct.c_int32), _p(ws, ct.c_int32))
+            )
+
+    def env_map_dims(self, map_id: int) -> tuple[int, int]:
+        """(height, width) of map `map_id` of the pool (reference: `MettaGrid.map_height / map_width`)."""
+        h, w = ct.c_int32(), ct.c_int32()
+        native.check(self.L.mg_map_dims(self._h, int(map_id), ct.byref(h), ct.byref(w)))
+        return int(h.value), int(w.value)
 
     def _stream(self) -> ct.c_void_p:
         return ct.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
@@ -110,7 +126,7 @@ class MettaGridBatch:
         ids = None if env_ids is None else np.ascontiguousarray(env_ids, dtype=np.int32)
         base = np.arange(self.num_envs) if env_ids is None else np.asarray(env_ids)
         s = np.ascontiguousarray(base if seeds is None else seeds, dtype=np.uint32)
-        m = np.ascontiguousarray(base % self.map_pool.shape[0] if map_ids is None else map_ids, dtype=np.int32)
+        m = np.ascontiguousarray(base % len(self.map_pool) if map_ids is None else map_ids, dtype=np.int32)
         if s.shape != (n,) or m.shape != (n,):
             raise RuntimeError("seeds / map_ids must have one entry per environment being reset")
         native.check(
@@ -141,6 +157,7 @@ class MettaGridBatch:
 
     def set_auto_reset(self, enabled: bool, map_stride: int = 1) -> None:
         native.check(self.L.mg_set_auto_reset(self._h, int(enabled), int(map_stride)))
+        self.map_stride = int(map_stride)
 
     def set_early_reset(self, steps: Optional[Sequence[int]]) -> None:
         if steps is None:
@@ -199,8 +216,10 @@ class MettaGridBatch:
         )  # fmt: skip
         return av, at, gv, gt
 
-    def agent_groups(self, env: int) -> list[int]:
+    def agent_groups(self, env: int, last_finished: bool = False) -> list[int]:
         mid = self.env_info(env)["map_id"]
+        if last_finished:  # the finished episode played the previous map of the rotation
+            mid = (mid - getattr(self, "map_stride", 1)) % len(self.map_pool)
         flat = self.map_pool[mid].reshape(-1)
         c = self.compiled
         return [c.cell_group[int(v) - 1] for v in flat if v != 0 and c.cell_kinds[int(v) - 1] == 2]
@@ -208,7 +227,7 @@ class MettaGridBatch:
     def get_episode_stats(self, env: int, last_finished: bool = False) -> dict:
         """`MettaGrid::get_episode_stats` (BIND/mettagrid_c.cpp:936-953) of one environment."""
         av, at, gv, gt = self.raw_stats(env, last_finished)
-        return decode_episode_stats(self.compiled, av, at, gv, gt, self.agent_groups(env))
+        return decode_episode_stats(self.compiled, av, at, gv, gt, self.agent_groups(env, last_finished))
 
     def agent_state(self, env: int) -> np.ndarray:
         R = len(self.compiled.resource_names)

@@ -42,7 +42,8 @@ struct KArgs {
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
   const int* map_nasm;        // [P]
   const float* map_objcount;  // [P][n_cells]
-  int P, H, W, HW, NAmax, n_cells;
+  const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
+  int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
   int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
   int CB;                  // bits needed for the largest per-object token count
   int TSW, TSA, TSS, HEAP; // token-list strides of walls / agents / assemblers; heap size in tokens
@@ -115,6 +116,14 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Maps of one pool may differ in size (navigation suite): the kernel's copy of the arguments takes the dimensions of
+// the map its environment plays.
+__device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
+  const int2 d = a.map_dims[map_id];
+  a.H = d.x;
+  a.W = d.y;
+}
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
                                            int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP) {
@@ -752,37 +761,6 @@ __device__ inline void mg_stage_rng(const KArgs& a, const Lds& l, int e, uint32_
   }
 }
 
-// Attempted token count of one agent's observation without writing it (used for the tokens_* stats of the
-// step-0 observation when an environment restarts inside the act kernel).  One lane per agent.
-__device__ inline int mg_count_agent_tokens(const KArgs& a, const Lds& l, const int4* asm_info, int ai) {
-  const int* dc = a.dc;
-  const DAgent* me = &l.ag[ai];
-  const int oh = dc[DC_OBS_H], ow = dc[DC_OBS_W], hr = oh >> 1, wr = ow >> 1;
-  const int ar = me->r, ac = me->c;
-  int n = (dc[DC_G_COMPLETION] ? 1 : 0) + (dc[DC_G_LAST_ACTION] ? 1 : 0) + (dc[DC_G_LAST_REWARD] ? 1 : 0);
-  if (dc[DC_G_GOAL]) n += L_n(dc, group_rec(dc, me->group)[GR_OFF_GOAL]);
-  if (dc[DC_G_COMPASS]) {
-    int dr = a.H / 2 - ar, dcc = a.W / 2 - ac;
-    int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
-    if ((sr != 0 || sc != 0) && hr + sr >= 0 && hr + sr < oh && wr + sc >= 0 && wr + sc < ow) n++;
-  }
-  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN];
-  const int r_start = max(ar - hr, 0), c_start = max(ac - wr, 0);
-  const int r_end = min(ar + hr + 1, a.H), c_end = min(ac + wr + 1, a.W);
-  for (int p = 0; p < P; p++) {
-    int packed = dc[op + p];
-    int r = ar + (packed & 0xFF) - 8, c = ac + ((packed >> 8) & 0xFF) - 8;
-    if (r < r_start || r >= r_end || c < c_start || c >= c_end) continue;
-    uint16_t cv = l.grid[r * a.W + c];
-    if (cv != 0) {
-      CountOut co{0};
-      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, CellCodec{a.NW, a.A}, a.H, a.W, 0, cv, co);
-      n += co.n;
-    }
-  }
-  return n;
-}
-
 // Restart a finished environment from the per-map templates (MettaGridPufferEnv.step -> _new_sim(),
 // mettagrid_puffer_env.py:158-164; same seed, next map).  All threads of the workgroup; HBM state only.
 __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid, int nt) {
@@ -833,10 +811,12 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
 __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   __shared__ uint32_t mtnext[624];
   const int lane = threadIdx.x, e = blockIdx.x + a.env_base;
-  const int A = a.A, H = a.H, W = a.W;
+  const int A = a.A;
   const int* dc = a.dc;
   DEnv env = a.env[e];
   if (a.auto_reset && env.done) mg_restart_env(a, e, env, lane, 64);  // wave-uniform
+  mg_use_map(a, env.map_id);
+  const int H = a.H, W = a.W;
   const bool active = lane < A;
   const size_t g = (size_t)e * A + (active ? lane : 0);
   DAgent* rec = a.agents + g;
@@ -1163,6 +1143,7 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   }
   if (DCL) a.dc = l.dc;
   Ctx cx;
+  mg_use_map(a, map_id);
   mg_make_ctx(a, l, cx, e, (int)map_id, step);
   cx.grid = nullptr;
   __syncthreads();
@@ -1257,6 +1238,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 
   const bool do_reset = a.auto_reset && env.done;  // block-uniform
   if (do_reset) mg_restart_env(a, e, env, tid, nt);
+  mg_use_map(a, env.map_id);
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
   uint4* dst = (uint4*)l.ag;
@@ -1363,6 +1345,7 @@ __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   }
   MG_STAMP(0);
   DEnv env = a.env[e];
+  mg_use_map(a, env.map_id);
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   {
     const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
@@ -1416,6 +1399,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   env.done = 0;
   env.error = 0;
   Ctx cx;
+  mg_use_map(a, env.map_id);
   mg_make_ctx(a, l, cx, e, (int)env.map_id, 0);
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   mg_reset_env(a, l, cx, e, (int)env.map_id, env.seed, tid, nt);
@@ -1538,6 +1522,7 @@ struct mg_handle {
   std::vector<hipEvent_t> ev;  // profiling ring: pairs (start, stop) per step
   size_t ev_count = 0;         // steps recorded since profiling was enabled
   std::vector<std::vector<int4>> host_spawn, host_asm;  // per map (inspection)
+  std::vector<int2> host_dims;                          // per map (height, width)
   int* d_list = nullptr;       // scratch for reset lists [3][E]
   int* d_inv = nullptr;        // scratch for set_inventory [2][MGD_MAX_R]
   uint8_t* masks = nullptr;    // all ones (reference: mettagrid_c.cpp:983-995)
@@ -1666,23 +1651,39 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   return 0;
 }
 
-int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int width) {
+static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths) {
   if (!h) return fail("mg_set_maps: NULL handle");
-  if (num_maps < 1 || height < 1 || width < 1) return fail("mg_set_maps: bad dimensions");
-  if (height > 65535 || width > 65535) return fail("mg_set_maps: map too large");
+  if (!maps || !heights || !widths) return fail("mg_set_maps: NULL argument");
+  if (num_maps < 1) return fail("mg_set_maps: bad dimensions");
+  int HWp = 0, Hmax = 0, Wmax = 0;
+  std::vector<size_t> src_off((size_t)num_maps);
+  {
+    size_t off = 0;
+    for (int m = 0; m < num_maps; m++) {
+      if (heights[m] < 1 || widths[m] < 1) return fail("mg_set_maps: bad dimensions");
+      if (heights[m] > 65535 || widths[m] > 65535) return fail("mg_set_maps: map too large");
+      if ((long long)heights[m] * widths[m] > (1 << 24)) return fail("mg_set_maps: map too large");
+      src_off[(size_t)m] = off;
+      off += (size_t)heights[m] * widths[m];
+      HWp = std::max(HWp, (heights[m] * widths[m] + 1) & ~1);  // keep each map 4-byte aligned
+      Hmax = std::max(Hmax, heights[m]);
+      Wmax = std::max(Wmax, widths[m]);
+    }
+  }
   HIPCHK(hipSetDevice(h->device));
   const MgConfig& c = h->cfg;
   KArgs& k = h->k;
-  const int HW = height * width;
-  const int HWp = (HW + 1) & ~1;  // keep each map 4-byte aligned
   const CellCodec codec{(int)c.walls.size(), c.A};
   std::vector<uint16_t> cells((size_t)num_maps * HWp, 0);
   std::vector<int4> spawn((size_t)num_maps * c.A);
   std::vector<std::vector<int4>> asm_lists((size_t)num_maps);
   std::vector<float> objcount((size_t)num_maps * c.cells.size(), 0.f);
   h->host_spawn.assign((size_t)num_maps, {});
+  std::vector<int2> dims((size_t)num_maps);
   for (int m = 0; m < num_maps; m++) {
-    const uint8_t* src = maps + (size_t)m * HW;
+    const uint8_t* src = maps + src_off[(size_t)m];
+    const int height = heights[m], width = widths[m];
+    dims[(size_t)m] = make_int2(height, width);
     uint32_t next_id = 1;
     int n_agents = 0;
     for (int r = 0; r < height; r++)
@@ -1755,7 +1756,11 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   for (void* p : h->map_allocs) (void)hipFree(p);
   h->map_allocs.clear();
-  uint16_t* d_cells; int4* d_spawn; int4* d_asm; int* d_nasm; float* d_obj; DAsm* d_asms;
+  uint16_t* d_cells; int4* d_spawn; int4* d_asm; int* d_nasm; float* d_obj; DAsm* d_asms; int2* d_dims;
+  if (dalloc(h, &d_dims, dims.size(), true)) return 1;
+  HIPCHK(hipMemcpy(d_dims, dims.data(), dims.size() * sizeof(int2), hipMemcpyHostToDevice));
+  k.map_dims = d_dims;
+  h->host_dims = dims;
   if (dalloc(h, &d_cells, cells.size(), true)) return 1;
   if (dalloc(h, &d_spawn, spawn.size(), true)) return 1;
   if (dalloc(h, &d_asm, asm_flat.size(), true)) return 1;
@@ -1769,7 +1774,7 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
   HIPCHK(hipMemcpy(d_obj, objcount.data(), objcount.size() * 4, hipMemcpyHostToDevice));
   k.map_cells = d_cells; k.map_spawn = d_spawn; k.map_asm = d_asm; k.map_nasm = d_nasm; k.map_objcount = d_obj;
   k.asms = d_asms;
-  k.P = num_maps; k.H = height; k.W = width; k.HW = HWp; k.NAmax = NAmax;
+  k.P = num_maps; k.H = Hmax; k.W = Wmax; k.HW = HWp; k.NAmax = NAmax;
   h->lds_bytes = lds;
   h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
@@ -1848,6 +1853,24 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
   h->maps_set = true;
+  return 0;
+}
+
+int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int width) {
+  if (num_maps < 1) return fail("mg_set_maps: bad dimensions");
+  std::vector<int32_t> hs((size_t)num_maps, height), ws((size_t)num_maps, width);
+  return mg_set_maps_impl(h, maps, num_maps, hs.data(), ws.data());
+}
+
+int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths) {
+  return mg_set_maps_impl(h, maps, num_maps, heights, widths);
+}
+
+int mg_map_dims(mg_handle* h, int map_id, int32_t* height, int32_t* width) {
+  if (!h || !height || !width) return fail("mg_map_dims: NULL argument");
+  if (!h->maps_set || map_id < 0 || map_id >= (int)h->host_dims.size()) return fail("mg_map_dims: map id out of range");
+  *height = h->host_dims[(size_t)map_id].x;
+  *width = h->host_dims[(size_t)map_id].y;
   return 0;
 }
 

@@ -233,8 +233,8 @@ class MettaGridDeviceVecEnv:
                     "per_label_rewards": dict(self._per_label_rewards),
                     "attributes": {
                         "seed": info["seed"],
-                        "map_w": b.map_width,
-                        "map_h": b.map_height,
+                        "map_w": int(b.map_dims[info["map_id"], 1]),
+                        "map_h": int(b.map_dims[info["map_id"], 0]),
                         "steps": info["current_step"],
                         "max_steps": self.cfg.game.max_steps,
                         "completion_time": time.time(),
@@ -253,6 +253,8 @@ class MettaGridDeviceVecEnv:
             self._episodes_seen[e] = int(table[e, 4])
             stats = b.get_episode_stats(e, last_finished=True)
             ep_rewards, steps = b.finished_rewards(e)
+            # the table already names the map of the episode that has just begun
+            prev_map = (int(table[e, 3]) - getattr(b, "map_stride", 1)) % len(b.map_pool)
             agent: dict[str, float] = {}
             for st in stats["agent"]:
                 for k, v in st.items():
@@ -264,7 +266,8 @@ class MettaGridDeviceVecEnv:
                     "agent": {k: v / A for k, v in agent.items()},
                     "per_label_rewards": dict(self._per_label_rewards),
                     "attributes": {
-                        "seed": int(table[e, 2]), "map_w": b.map_width, "map_h": b.map_height, "steps": steps,
+                        "seed": int(table[e, 2]), "map_w": int(b.map_dims[prev_map, 1]),
+                        "map_h": int(b.map_dims[prev_map, 0]), "steps": steps,
                         "max_steps": self.cfg.game.max_steps, "completion_time": time.time(),
                     },
                 }

@@ -210,6 +210,46 @@ def test_auto_reset_matches_puffer_semantics():
     b.close()
 
 
+def test_mixed_map_sizes_vs_oracle():
+    """BASELINE config 3 (navigation suite): one pool holding maps of different sizes.  Bounds, the compass token
+    (towards the centre of the map being played) and auto-reset across sizes against one oracle per (env, map)."""
+    from metta_amd.mapgen import RandomMapBuilder
+    from oracle.mg_oracle import make_oracle_env
+
+    cfg = make_navigation(4)
+    cfg.game.global_obs.compass = True
+    cfg.game.max_steps = 40
+    shapes = [(12, 17), (31, 20), (9, 9), (44, 72), (20, 88), (15, 14)]
+    maps = [
+        RandomMapBuilder(width=w, height=h, border_width=1, agents=4, objects={"wall": (h * w) // 9, "assembler": 3}).build(
+            np.random.default_rng(100 + i)
+        )
+        for i, (h, w) in enumerate(shapes)
+    ]
+    E, A = 9, 4
+    seeds = [50 + e for e in range(E)]
+    cur_map = [e % len(maps) for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, list(cur_map))
+    b.set_auto_reset(True, 1)
+    assert b.env_map_dims(3) == (44, 72) and b.env_map_dims(2) == (9, 9)
+    comp = compile_game(cfg, init_obs_passes=2)
+    oras = [make_oracle_env(comp, comp.encode_map(maps[m]), s) for s, m in zip(seeds, cur_map)]
+    nA = len(comp.action_names)
+    _compare_step(b, oras, 0, A)
+    rs = np.random.RandomState(11)
+    for t in range(1, 130):
+        acts = np.where(rs.rand(E, A) < 0.85, rs.randint(0, 5, size=(E, A)), rs.randint(0, nA, size=(E, A))).astype(np.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + 1) % len(maps)
+                oras[e] = make_oracle_env(comp, comp.encode_map(maps[cur_map[e]]), seeds[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+    _compare_state(b, oras, 129)
+    b.close()
+
+
 def test_vs_reference_core():
     """HIP against the reference's own compiled C++ core (oracle/_ref), when it travelled with the tree."""
     from oracle.ref_bridge import RefEnv, have_reference
