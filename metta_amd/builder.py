@@ -8,6 +8,7 @@ from metta_amd.config import (
     AgentRewards,
     AssemblerConfig,
     AttackActionConfig,
+    AttackOutcome,
     ChangeVibeActionConfig,
     GameConfig,
     InventoryConfig,
@@ -91,4 +92,62 @@ def make_navigation(num_agents: int) -> MettaGridConfig:
             agent=AgentConfig(rewards=AgentRewards(inventory={"heart": 1})),
             map_builder=RandomMapBuilder(agents=num_agents),
         )
+    )
+
+
+def make_combat_stress(num_agents: int = 1024, size: int = 256, teams: int = 2) -> MettaGridConfig:
+    """BASELINE config 4: a large-map combat stress case.  The reference has no factory for it; this one
+    is the arena building set on a `size x size` random map with `teams` teams, change_vibe enabled over three
+    vibes, and an attack that fires from a move under the `weapon` vibe: costs a laser, blocked by armor (+1 when the
+    target vibes `armor`), freezes for 10 ticks and loots hearts and ore."""
+    from metta_amd.mapgen import RandomMapBuilder
+
+    per = num_agents // teams
+    assert per * teams == num_agents
+    actions = ActionsConfig(
+        noop=NoopActionConfig(),
+        move=MoveActionConfig(),
+        attack=AttackActionConfig(
+            consumed_resources={"laser": 1},
+            defense_resources={"armor": 1},
+            success=AttackOutcome(freeze=10, loot=["heart", "ore_red"]),
+            vibes=["weapon"],
+            vibe_bonus={"armor": 1},
+        ),
+        change_vibe=ChangeVibeActionConfig(vibes=["default", "weapon", "armor"], enabled=True),
+    )
+    agents = [
+        AgentConfig(
+            team_id=t,
+            inventory=InventoryConfig(
+                default_limit=50,
+                limits={"heart": ResourceLimitsConfig(limit=255, resources=["heart"])},
+                initial={"laser": 3, "armor": 1, "ore_red": 2},
+            ),
+            rewards=AgentRewards(inventory={"heart": 1}),
+            freeze_duration=10,
+        )
+        for t in range(teams)
+        for _ in range(per)
+    ]
+    cells = size * size
+    return MettaGridConfig(
+        label="combat_stress",
+        game=GameConfig(
+            num_agents=num_agents,
+            max_steps=1000,
+            actions=actions,
+            objects=arena_objects(),
+            agents=agents,
+            map_builder=RandomMapBuilder(
+                width=size,
+                height=size,
+                border_width=1,
+                agents={("team_%d" % t): per for t in range(teams)},
+                objects={
+                    "wall": cells // 12, "assembler": cells // 400, "mine_red": cells // 200,
+                    "generator_red": cells // 400, "lasery": cells // 800, "armory": cells // 800,
+                },
+            ),
+        ),
     )

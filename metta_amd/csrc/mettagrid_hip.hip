@@ -42,6 +42,7 @@ struct KArgs {
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
   const int* map_nasm;        // [P]
   const float* map_objcount;  // [P][n_cells]
+  uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
   int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
   int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
@@ -126,7 +127,8 @@ __device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
 }
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
-                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP) {
+                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1) {
+  if (a_rec < 0) a_rec = A;  // agent records staged in LDS (0: the kernel works on the records in HBM)
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -139,7 +141,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->dc = (int*)(base + dco);
     l->tmp = (int*)(base + tmpo);
   }
-  size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t g = take((size_t)HW * 2), ag = take((size_t)a_rec * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
@@ -159,7 +161,8 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
 
 // LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
 __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
-                                               int dcw, int NOBJ, int HEAP, int NP) {
+                                               int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1) {
+  if (a_rec < 0) a_rec = A;
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
@@ -168,7 +171,7 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   };
   size_t dco = take((size_t)dcw * 4);
   if (l) l->dc = (int*)(base + dco);
-  size_t g = take((size_t)HW * 2), ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t g = take((size_t)HW * 2), ag = take((size_t)a_rec * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take((size_t)NOBJ * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
   // the static assembler info is only read while the token lists are built, the row buffers only afterwards
@@ -1220,12 +1223,15 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
 // sequential order on LDS state (bindings/mettagrid_c.cpp:572-650).
 // ------------------------------------------------------------------------------------------------------------
 #define MG_ACT_THREADS 64
-template <bool DCL>
+// BIG: the map does not fit LDS next to the records (256 x 256, 1024 agents): the env's grid
+// lives in an HBM scratch tile (served by L2), everything else as usual.
+template <bool DCL, bool BIG>
 __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
+  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
+  if (BIG) l.grid = a.big_grid + (size_t)e * a.HW;
   MG_STAMP(8);
   if (DCL) {
     for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
@@ -1333,12 +1339,18 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 // kernel 2: observations + rewards + episode flags.  One workgroup (4 waves) per environment; each wave encodes
 // whole agents' token rows in LDS and streams them to HBM (bindings/mettagrid_c.cpp:652-677).
 // ------------------------------------------------------------------------------------------------------------
-template <bool DCL>
-__global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
+// BIG: grid tile and agent records are read in HBM (through L2); the token lists still live in LDS.
+template <bool DCL, bool BIG>
+__global__ __launch_bounds__(MG_THREADS, BIG ? 1 : 8) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve_obs(smem, &l, a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
+  mg_carve_obs(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
+               a.dc[DC_PATTERN_N], BIG ? 0 : a.A);
+  if (BIG) {
+    l.grid = a.big_grid + (size_t)e * a.HW;
+    l.ag = a.agents + (size_t)e * a.A;
+  }
   if (DCL) {
     for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
     a.dc = l.dc;
@@ -1348,9 +1360,11 @@ __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
   mg_use_map(a, env.map_id);
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   {
-    const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
-    uint4* dst = (uint4*)l.ag;
-    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    if (!BIG) {
+      const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
+      uint4* dst = (uint4*)l.ag;
+      for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    }
     const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
     uint4* d2 = (uint4*)l.as;
     for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
@@ -1385,12 +1399,18 @@ __global__ __launch_bounds__(MG_THREADS, 8) void mg_obs_kernel(KArgs a) {
 }
 
 // Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.
+template <bool BIG>
 __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP, a.dc[DC_PATTERN_N]);
+  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP,
+           a.dc[DC_PATTERN_N], BIG ? 0 : a.A);
+  if (BIG) {
+    l.grid = a.big_grid + (size_t)e * a.HW;
+    l.ag = a.agents + (size_t)e * a.A;
+  }
   DEnv env = a.env[e];
   env.seed = a.reset_seeds[blockIdx.x];
   env.map_id = (uint32_t)a.reset_maps[blockIdx.x];
@@ -1423,9 +1443,11 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   }
   __syncthreads();
   mg_flush_stats(a, l, cx, e, tid, nt);
-  uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
-  const uint4* src = (const uint4*)l.ag;
-  for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+  if (!BIG) {
+    uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
+    const uint4* src = (const uint4*)l.ag;
+    for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+  }
   uint4* d2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
   const uint4* s2 = (const uint4*)l.as;
   for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
@@ -1514,6 +1536,7 @@ struct mg_handle {
   std::vector<void*> map_allocs;
   size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0;
   bool dc_lds = false;
+  bool big = false;                // map tile too large for LDS: grid (and, for obs/reset, agent records) in HBM
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1751,9 +1774,18 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     k.CB = 1;
     while ((1 << k.CB) <= mx) k.CB++;
   }
+  if (HEAP > 65535) return fail("mg_set_maps: token lists of one environment exceed 65535 entries");
+  // LDS plan.  Normal: map tile + records + token lists in LDS.  BIG (the map does not fit): the grid tile of each
+  // env lives in HBM, and the observation / reset kernels read the agent records in HBM too.
+  const size_t LDS_MAX = 160 * 1024;
+  bool big = false;
   size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
-  if (lds > 160 * 1024)
-    return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
+  if (lds > LDS_MAX) {
+    big = true;
+    lds = mg_carve(nullptr, nullptr, 0, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, 0);
+    if (lds > LDS_MAX)
+      return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
+  }
   for (void* p : h->map_allocs) (void)hipFree(p);
   h->map_allocs.clear();
   uint16_t* d_cells; int4* d_spawn; int4* d_asm; int* d_nasm; float* d_obj; DAsm* d_asms; int2* d_dims;
@@ -1776,27 +1808,42 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   k.asms = d_asms;
   k.P = num_maps; k.H = Hmax; k.W = Wmax; k.HW = HWp; k.NAmax = NAmax;
   h->lds_bytes = lds;
-  h->dc_lds = k.dc_words <= MG_DC_LDS_MAX_WORDS;
+  h->big = big;
+  k.big_grid = nullptr;
+  if (big) {
+    uint16_t* bg = nullptr;
+    if (dalloc(h, &bg, (size_t)std::max(h->E, num_maps) * HWp, true)) return 1;
+    k.big_grid = bg;
+  }
+  const int hw_lds = big ? 0 : HWp, a_rec_obs = big ? 0 : c.A;
+  h->dc_lds = !big && k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
   int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
-  h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP);
-  if (h->lds_act > 160 * 1024 || h->lds_obs > 160 * 1024) {
+  h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs);
+  if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX) {
     h->dc_lds = false;
-    h->lds_act = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
-    h->lds_obs = mg_carve_obs(nullptr, nullptr, HWp, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
+    h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
+    h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs);
   }
+  if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX)
+    return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
+                ", obs " + std::to_string(h->lds_obs) + " bytes)");
   h->lds_uses = mg_carve_uses(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
-  if (h->dc_lds) {
-    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
-    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_uses));
-    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
-  } else {
-    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_act));
-    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_uses));
-    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_obs));
+  {
+    // the cap on dynamic LDS is a per-function setting shared by every handle of the process: raise it once
+    const int cap = (int)LDS_MAX;
+    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_act_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_uses_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_obs_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+    HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
   }
-  HIPCHK(hipFuncSetAttribute((const void*)mg_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // ---- episode-start templates: run the reset kernel once per map into template buffers ------------------
   {
     const size_t P = (size_t)num_maps, PA = P * c.A;
@@ -1841,7 +1888,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
       kt.reset_envs = nullptr;
       kt.reset_seeds = d_seeds;
       kt.reset_maps = d_maps;
-      hipLaunchKernelGGL(mg_reset_kernel, dim3((unsigned)P), dim3(MG_THREADS), h->lds_bytes, 0, kt);
+      if (h->big) hipLaunchKernelGGL(mg_reset_kernel<true>, dim3((unsigned)P), dim3(MG_THREADS), h->lds_bytes, 0, kt);
+      else hipLaunchKernelGGL(mg_reset_kernel<false>, dim3((unsigned)P), dim3(MG_THREADS), h->lds_bytes, 0, kt);
       hipError_t e2 = hipGetLastError();
       hipError_t e3 = hipDeviceSynchronize();
       if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
@@ -1895,7 +1943,8 @@ int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds,
   k.reset_envs = env_ids ? d : nullptr;
   k.reset_seeds = (const uint32_t*)(d + h->E);
   k.reset_maps = d + 2 * (size_t)h->E;
-  hipLaunchKernelGGL(mg_reset_kernel, dim3((unsigned)n), dim3(MG_THREADS), h->lds_bytes, s, k);
+  if (h->big) hipLaunchKernelGGL(mg_reset_kernel<true>, dim3((unsigned)n), dim3(MG_THREADS), h->lds_bytes, s, k);
+  else hipLaunchKernelGGL(mg_reset_kernel<false>, dim3((unsigned)n), dim3(MG_THREADS), h->lds_bytes, s, k);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));  // the scratch lists are reused by the next call
   return 0;
@@ -1930,12 +1979,14 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
       if (h->dc_lds) hipLaunchKernelGGL(mg_uses_kernel<true>, dim3(n), dim3(MG_USES_THREADS), h->lds_uses, st, kg);
       else hipLaunchKernelGGL(mg_uses_kernel<false>, dim3(n), dim3(MG_USES_THREADS), h->lds_uses, st, kg);
     } else {
-      if (h->dc_lds) hipLaunchKernelGGL(mg_act_kernel<true>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
-      else hipLaunchKernelGGL(mg_act_kernel<false>, dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      if (h->big) hipLaunchKernelGGL((mg_act_kernel<false, true>), dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      else if (h->dc_lds) hipLaunchKernelGGL((mg_act_kernel<true, false>), dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
+      else hipLaunchKernelGGL((mg_act_kernel<false, false>), dim3(n), dim3(MG_ACT_THREADS), h->lds_act, st, kg);
     }
     if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
-    if (h->dc_lds) hipLaunchKernelGGL(mg_obs_kernel<true>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
-    else hipLaunchKernelGGL(mg_obs_kernel<false>, dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    if (h->big) hipLaunchKernelGGL((mg_obs_kernel<false, true>), dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    else if (h->dc_lds) hipLaunchKernelGGL((mg_obs_kernel<true, false>), dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
+    else hipLaunchKernelGGL((mg_obs_kernel<false, false>), dim3(n), dim3(MG_THREADS), h->lds_obs, st, kg);
     if (gi > 0) {
       (void)hipEventRecord(h->ev_join[gi - 1], st);
       (void)hipStreamWaitEvent(s, h->ev_join[gi - 1], 0);

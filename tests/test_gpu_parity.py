@@ -8,7 +8,7 @@ exactly representable f32 values here, so we require equality, which is stricter
 import numpy as np
 import pytest
 
-from metta_amd.builder import make_arena, make_navigation
+from metta_amd.builder import make_arena, make_combat_stress, make_navigation
 from metta_amd.compile import compile_game
 from tests.fuzz_configs import fuzz_actions, rand_cfg
 from tests.helpers import digest, fixture_actions, fixture_grid, load_fixture, load_map_pool, stats_equal
@@ -247,6 +247,43 @@ def test_mixed_map_sizes_vs_oracle():
         b.step(acts.reshape(-1))
         _compare_step(b, oras, t, A)
     _compare_state(b, oras, 129)
+    b.close()
+
+
+@pytest.mark.parametrize(
+    "agents,size,envs,steps",
+    [(1024, 256, 2, 60), (256, 48, 3, 120), (32, 300, 2, 60)],
+    ids=["256x256x1024-hbm-grid", "48x48x256-dense", "300x300x32-hbm-grid"],
+)
+def test_combat_stress_vs_oracle(agents, size, envs, steps):
+    """BASELINE config 4: large-map combat (attack under the weapon vibe, armor defence with vibe bonus, freeze, loot,
+    swaps with frozen agents, assembler cooldowns).  At 256 x 256 x 1024 agents and at 300 x 300 the map tile does not
+    fit LDS: the kernels keep each environment's grid (and, for observations, the agent records) in HBM."""
+    cfg = make_combat_stress(agents, size)
+    cfg.game.max_steps = 50  # the episode end and the auto-reset (template restart) are part of the run
+    maps = [cfg.game.map_builder.build(np.random.default_rng(7 + i)) for i in range(2)]
+    seeds = [900 + e for e in range(envs)]
+    cur_map = [e % 2 for e in range(envs)]
+    b = _batch(cfg, maps, envs, seeds, list(cur_map))
+    comp, oras = _oracles(cfg, maps, seeds, cur_map)
+    from oracle.mg_oracle import make_oracle_env
+
+    nA = len(comp.action_names)
+    _compare_step(b, oras, 0, agents)
+    rs = np.random.RandomState(21)
+    for t in range(1, steps + 1):
+        acts = np.where(rs.rand(envs, agents) < 0.7, rs.randint(1, 5, size=(envs, agents)), rs.randint(0, nA, size=(envs, agents)))
+        acts = acts.astype(np.int32)
+        for e in range(envs):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + 1) % 2
+                oras[e] = make_oracle_env(comp, comp.encode_map(maps[cur_map[e]]), seeds[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, agents)
+        if t % 40 == 0:
+            _compare_state(b, oras, t)
+    _compare_state(b, oras, steps)
     b.close()
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_ablate.sh "<diag values>"  -- obs-kernel time under MG_DIAG ablations (results are wrong on purpose)
+# usage: tools/ablate.sh "<diag values>"  -- obs-kernel time under MG_DIAG ablations (results are wrong on purpose)
 export TMPDIR=/tmp
 for d in $1; do
   mkdir -p gpurun_out/abl_$d

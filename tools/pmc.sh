@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>"   -- one PMC pass over a short bench run
+# usage: tools/pmc.sh <tag> "<counters>"   -- one PMC pass over a short bench run
 tag=$1; ctrs=$2
 export TMPDIR=/tmp
 R=$PWD

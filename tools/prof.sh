@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> [extra bench args]   (runs on the GPU box under gpurun)
+# usage: tools/prof.sh <tag> [extra bench args]   (runs on the GPU box under gpurun)
 tag=$1; shift
 export TMPDIR=/tmp
 R=$PWD

@@ -1,10 +1,10 @@
 import sys, json, ctypes as ct
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0,''+str(__import__("pathlib").Path(__file__).resolve().parents[1])+'')
 import numpy as np, torch
 from metta_amd.batch import MettaGridBatch
 from metta_amd.builder import make_arena
 from metta_amd import native
-z=np.load('/root/repo/tests/golden/arena24_map_pool.npz'); meta=json.loads(bytes(z['meta']).decode()); names=np.array(meta['cell_names']); pool=[names[m] for m in z['maps']]
+z=np.load(''+str(__import__("pathlib").Path(__file__).resolve().parents[1])+'/tests/golden/arena24_map_pool.npz'); meta=json.loads(bytes(z['meta']).decode()); names=np.array(meta['cell_names']); pool=[names[m] for m in z['maps']]
 E=4096
 b=MettaGridBatch(make_arena(24),E,pool,seeds=list(range(E)),map_ids=[e%64 for e in range(E)])
 tab=torch.randint(0,5,(64,E*24),device='cuda',dtype=torch.int32)
