@@ -3,6 +3,7 @@
 
   python3 tools/bench_configs.py navigation   # 8192 envs x 4 agents, 64 maps of mixed sizes (60..120)^2
   python3 tools/bench_configs.py combat       # 64 envs x 1024 agents on 256 x 256 maps (grid tiles in HBM)
+  python3 tools/bench_configs.py rollout      # configs[4] on one GPU: 4096 arena envs x 24 agents + LSTM policy (bf16)
 """
 import json
 import sys
@@ -22,6 +23,8 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "navigation"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     rs = np.random.RandomState(0)
+    if which == "rollout":
+        return rollout_bench(steps)
     if which == "navigation":
         A, E = 4, 8192
         cfg = make_navigation(A)
@@ -53,6 +56,28 @@ def main():
     print(json.dumps({"workload": which, "envs": E, "agents_per_env": A, "steps": steps, "ms_per_step": dt / steps * 1e3,
                       "kernel_ms_mean": float(ms.mean()), "agent_steps_per_s": E * A * steps / dt}))
     b.close()
+
+
+def rollout_bench(steps):
+    from metta_amd.builder import make_arena
+    from metta_amd.rollout import LSTMPolicy, rollout
+    from metta_amd.vecenv import MettaGridDeviceVecEnv
+
+    z = np.load(Path(__file__).resolve().parents[1] / "tests" / "golden" / "arena24_map_pool.npz", allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    names = np.array(meta["cell_names"])
+    pool = [names[m] for m in z["maps"]]
+    cfg = make_arena(24)
+    env = MettaGridDeviceVecEnv(cfg, 4096, maps=pool, device=0)
+    env.stats_every = 64
+    env.async_reset(0)
+    pol = LSTMPolicy(200, env.single_action_space.n).to("cuda").to(torch.bfloat16)
+    rollout(env, pol, 5)
+    n, dt, _, infos = rollout(env, pol, steps)
+    print(json.dumps({"workload": "rollout (env step + LSTM policy forward + sampling, bf16)", "envs": 4096,
+                      "agents_per_env": 24, "steps": steps, "ms_per_step": dt / steps * 1e3,
+                      "agent_steps_per_s": n / dt, "episode_infos": len(infos)}))
+    env.close()
 
 
 if __name__ == "__main__":
