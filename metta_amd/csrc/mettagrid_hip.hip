@@ -1305,6 +1305,8 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
         }
       }
     }
+    if (dc[DC_HAS_DAMAGE])  // bindings/mettagrid_c.cpp:642-650: after regeneration, agent order
+      for (int ai = 0; ai < a.A; ai++) mg_check_damage(cx, ai, rng);
     l.flags[0] = rng.used;
     l.flags[1] = rng.overflow;
     l.flags[2] = cx.asm_dirty;
@@ -1583,9 +1585,9 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   const MgConfig& c = h->cfg;
   if (c.R > MGD_MAX_R) return fail("mg_create: more than 16 resources are not supported on the device path yet");
   if (!c.chests.empty()) return fail("mg_create: chest objects are not supported on the device path yet (SURVEY A19)");
+  bool has_damage = false;
   for (const auto& g : c.groups)
-    if (!g.damage_threshold.empty() && !g.damage_resources.empty())
-      return fail("mg_create: agent damage is not supported on the device path yet");
+    if (!g.damage_threshold.empty() && !g.damage_resources.empty()) has_damage = true;
   if (c.A > 8191) return fail("mg_create: too many agents per environment");
   for (const auto& a : c.assemblers) {
     if (a.chest_search_distance > 0 && !c.chests.empty()) return fail("mg_create: chest search unsupported");
@@ -1603,13 +1605,16 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   memset(&k, 0, sizeof(k));
   k.E = num_envs; k.A = c.A; k.T = c.T; k.SA = c.n_agent_slots; k.SG = c.n_game_slots; k.R = c.R; k.NG = c.n_group_names;
   k.TW = (k.SA + 31) / 32; k.GW = (k.SG + 31) / 32; k.n_cells = (int)c.cells.size();
-  k.NWIN = std::min(624, c.A / 2 + 2 + MG_WIN_MARGIN);
-  if (c.A / 2 + 2 > 624) return fail("mg_create: too many agents for the RNG window");
+  // MT19937 outputs one step may consume: the shuffle's draws (+ rare redraws) and, with damage configured, one
+  // canonical double (two outputs) per agent (agent.cpp:134-177)
+  const int max_draws = c.A / 2 + 2 + (has_damage ? 2 * c.A : 0);
+  k.NWIN = std::min(624, max_draws + MG_WIN_MARGIN);
+  if (max_draws > 624) return fail("mg_create: too many agents for the RNG window");
   k.ROWB = (int)mg_align16((size_t)c.T * 3) + 16;  // + the row's 16-byte phase in HBM (mg_encode_all)
   k.auto_reset = 1; k.map_stride = 1;
   {
     // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
-    bool ok = c.A <= 64 && c.regen_interval == 0;
+    bool ok = c.A <= 64 && c.regen_interval == 0 && !has_damage;
     for (int v : c.vibe_handler) ok = ok && v == 0;
     for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
     const char* dg = getenv("MG_DIAG");

@@ -14,7 +14,7 @@ enum MgDc {
   DC_R = 0, DC_A, DC_OBS_W, DC_OBS_H, DC_T, DC_TOKEN_BASE, DC_MAX_STEPS, DC_TRUNCATES,
   DC_G_COMPLETION, DC_G_LAST_ACTION, DC_G_LAST_REWARD, DC_G_COMPASS, DC_G_GOAL, DC_PROTO_OBS,
   DC_REGEN_INTERVAL, DC_INIT_PASSES, DC_N_VIBES, DC_NG, DC_N_INV_TOKENS, DC_N_ACTIONS, DC_MAX_PRIORITY,
-  DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE,
+  DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE, DC_HAS_DAMAGE,
   DC_OBS_WORDS,  // the stream's prefix that the observation kernel needs (action/attack/transfer tables come after it)
   DC_FID0,
   DC_OFF_FID_INV = DC_FID0 + MG_F_COUNT, DC_OFF_FID_IN, DC_OFF_FID_OUT, DC_OFF_ACTIONS,
@@ -28,7 +28,7 @@ enum MgDc {
 enum MgGr {
   GR_GROUP_ID = 0, GR_NAME_IDX, GR_FREEZE_DURATION, GR_INITIAL_VIBE, GR_OFF_TAGS, GR_N_LIMITS, GR_OFF_LIMITS,
   GR_OFF_LIMIT_OF, GR_OFF_MODIFIER, GR_OFF_LIMITS_ORDER, GR_OFF_INITIAL, GR_OFF_STAT_REWARDS, GR_OFF_GOAL,
-  GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_WORDS
+  GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_OFF_DMG_THRESHOLD, GR_OFF_DMG_RESOURCES, GR_WORDS
 };
 enum MgWr { WR_TYPE_ID = 0, WR_VIBE, WR_OFF_TAGS, WR_WORDS };
 enum MgAr {
@@ -102,6 +102,9 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
   H(DC_SA) = c.n_agent_slots; H(DC_SG) = c.n_game_slots; H(DC_N_GROUPS) = (int)c.groups.size();
   H(DC_N_WALLS) = (int)c.walls.size(); H(DC_N_ASMS) = (int)c.assemblers.size(); H(DC_N_CELLS) = (int)c.cells.size();
   H(DC_HAS_DEFENSE) = c.atk_defense.empty() ? 0 : 1;
+  H(DC_HAS_DAMAGE) = 0;
+  for (const auto& g : c.groups)
+    if (!g.damage_threshold.empty() && !g.damage_resources.empty()) H(DC_HAS_DAMAGE) = 1;
   for (int i = 0; i < MG_F_COUNT; i++) H(DC_FID0 + i) = c.fid[i];
   { int o = b.put_list(c.fid_inv); H(DC_OFF_FID_INV) = o + 1; }
   { int o = b.put_list(c.fid_in); H(DC_OFF_FID_IN) = o + 1; }
@@ -152,6 +155,8 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
       int32_t dm = 0;
       for (int32_t r : g.diversity) dm |= (1 << r);
       rec[GR_DIVERSITY_MASK] = dm;
+      rec[GR_OFF_DMG_THRESHOLD] = b.put_kv(g.damage_threshold);
+      rec[GR_OFF_DMG_RESOURCES] = b.put_kv(g.damage_resources);
       int o = b.reserve(GR_WORDS);
       for (int i = 0; i < GR_WORDS; i++) b.w[(size_t)o + (size_t)i] = rec[i];
       table.push_back(o);

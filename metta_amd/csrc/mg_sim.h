@@ -764,6 +764,13 @@ struct RngWin {  // window of pre-tempered outputs staged in LDS
     }
     return win[used++];
   }
+  __device__ double canonical() {  // std::generate_canonical<double, 53> over a 32-bit engine: two outputs
+    double a = (double)next();
+    double b = (double)next();
+    double r = (a + b * 4294967296.0) / 18446744073709551616.0;
+    if (r >= 1.0) r = 0.99999999999999988897769753748;  // nextafter(1.0, 0.0)
+    return r;
+  }
   __device__ uint32_t bounded(uint32_t range) {  // uniform_int_dist.h:258-269
     unsigned long long product = (unsigned long long)next() * range;
     uint32_t low = (uint32_t)product;
@@ -806,6 +813,63 @@ __device__ inline void mg_shuffle(uint16_t* v, int n, RngWin& g) {
 
 // ---- observation tokens --------------------------------------------------------------------------------------
 // Number of tokens of inventory item with `amount` (observation_encoder.hpp:165-180)
+// Agent::check_and_apply_damage (agent.cpp:134-177): when every threshold resource is held, pay the thresholds and
+// lose one unit of a resource drawn by std::discrete_distribution over the amounts above the protected minimum
+// (random.tcc:2656-2713: cumulative probabilities in double, last forced to 1, lower_bound of a canonical draw).
+__device__ inline void mg_check_damage(Ctx& cx, int ai, RngWin& rng) {
+  const int* dc = cx.dc;
+  DAgent* a = &cx.ag[ai];
+  const int* gr = group_rec(dc, a->group);
+  const int ot = gr[GR_OFF_DMG_THRESHOLD], orr = gr[GR_OFF_DMG_RESOURCES];
+  const int nt = L_n(dc, ot), nr = L_n(dc, orr);
+  if (nt == 0 || nr == 0) return;
+  for (int i = 0; i < nt; i++)
+    if ((int)a->amt[KV_k(dc, ot, i)] < (KV_v(dc, ot, i) & 0xFFFF)) return;
+  for (int i = 0; i < nt; i++) inv_update(cx, ai, KV_k(dc, ot, i), -KV_v(dc, ot, i));
+  int n_avail = 0;
+  double sum = 0.0;
+  for (int i = 0; i < nr; i++) {
+    int removable = (int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i);
+    if (removable > 0) {
+      n_avail++;
+      sum += (double)removable;
+    }
+  }
+  if (n_avail > 0) {
+    int sel = 0;
+    if (n_avail >= 2) {
+      const double p = rng.canonical();
+      double acc = 0.0;
+      int seen = 0;
+      sel = n_avail - 1;  // the last cumulative probability is forced to 1
+      for (int i = 0; i < nr; i++) {
+        int removable = (int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i);
+        if (removable <= 0) continue;
+        acc += (double)removable / sum;
+        if (seen < n_avail - 1 && !(acc < p)) {  // lower_bound: first cumulative value >= p
+          sel = seen;
+          break;
+        }
+        seen++;
+      }
+    }
+    int item = -1, seen = 0;
+    for (int i = 0; i < nr; i++) {
+      int removable = (int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i);
+      if (removable <= 0) continue;
+      if (seen == sel) {
+        item = KV_k(dc, orr, i);
+        break;
+      }
+      seen++;
+    }
+    inv_update(cx, ai, item, -1);
+    mg_stat_add(cx, ai, cx.AS.damage_items_lost(), 1);
+    mg_stat_add(cx, ai, cx.AS.damaged(item), 1);
+  }
+  mg_stat_add(cx, ai, cx.AS.damage_triggered(), 1);
+}
+
 __device__ __forceinline__ int mg_inv_ntok(int amount, int base, int n_inv_tokens) {
   int n = 1;
   unsigned rem = (unsigned)amount / (unsigned)base;

@@ -4,7 +4,7 @@ Small crowded maps so that every interaction of the step path fires within a few
 attack (defense / armor / weapon / loot / freeze / swap with frozen agents), transfer, assembler protocols with
 vibes, min_agents, partial usage and max_uses, shared limits with modifiers, regeneration, initial inventories,
 compass / goal tokens, odd and even observation windows, tiny token budgets (dropped tokens) and token bases
-10/16/100/256.  `device_safe=True` leaves out chests and damage (not on the device path yet).
+10/16/100/256.  `device_safe=True` leaves out chests (not on the device path yet).
 """
 
 from __future__ import annotations
@@ -102,7 +102,7 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridC
         want_dmg = rs.randint(3) == 0
         th = {R[0]: int(rs.randint(1, 4))}
         rsrc = {r: int(rs.randint(0, 2)) for r in R[1 : 1 + rs.randint(1, 3)]}
-        if want_dmg and not device_safe:
+        if want_dmg:
             dmg = DamageConfig(threshold=th, resources=rsrc)
         regen = {}
         if rs.randint(2):

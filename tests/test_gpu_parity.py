@@ -94,7 +94,7 @@ def test_arena_vs_oracle(path_env, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_fuzz_vs_oracle(seed):
     rs = np.random.RandomState(seed)
     cfg = rand_cfg(rs, device_safe=True)
