@@ -99,6 +99,11 @@ int mg_episode_stats(mg_handle* h, int env, int last_finished, float* agent_valu
                      float* game_values, uint8_t* game_touched, void* stream);
 int mg_stat_slots(mg_handle* h, int* n_agent_slots, int* n_game_slots);
 
+/* Chests of `env` (the Chest entries of `MettaGrid::grid_objects`, mettagrid_c.cpp:754-918; chest.hpp:20-147), in
+ * row-major map order: out i32[n][5 + 2R] = {r, c, chest config index, object id, n_items, (item, amount) pairs in the
+ * inventory's iteration order, -1 padded}.  `*n_chests` receives the count; `out` may be NULL to query it. */
+int mg_chest_state(mg_handle* h, int env, int32_t* out, int max_chests, int32_t* n_chests, void* stream);
+
 /* Inspection (reference: `grid_objects`, mettagrid_c.cpp:754-918; `current_step`).  Host outputs; synchronises.
  * agent_state: i32 [A][9 + 2R]: r, c, prev_r, prev_c, frozen, vibe, steps_without_motion, object id, n_items,
  * then (item, amount) pairs in inventory iteration order (unused = -1).

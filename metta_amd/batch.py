@@ -244,6 +244,16 @@ class MettaGridBatch:
             native.check(self.L.mg_assembler_state(self._h, env, _p(out, ct.c_int32), self._stream()))
         return out[:n]
 
+    def chest_state(self, env: int) -> np.ndarray:
+        """[n][5 + 2R]: r, c, chest config index, object id, n_items, (item, amount) in inventory order."""
+        n = ct.c_int32()
+        native.check(self.L.mg_chest_state(self._h, env, None, 0, ct.byref(n), self._stream()))
+        R = len(self.compiled.resource_names)
+        out = np.zeros((max(n.value, 1), 5 + 2 * R), np.int32)
+        if n.value:
+            native.check(self.L.mg_chest_state(self._h, env, _p(out, ct.c_int32), n.value, ct.byref(n), self._stream()))
+        return out[: n.value]
+
     def set_inventory(self, env: int, agent: int, inventory: dict[int, int]) -> None:
         keys = order_from_pydict(list(inventory.keys()))
         items = np.asarray(keys, dtype=np.int32)

@@ -26,6 +26,9 @@
 #include "mg_sim.h"
 
 #define MG_THREADS 256
+#ifndef MG_OBS_WAVES
+#define MG_OBS_WAVES 8
+#endif
 #define MG_WIN_MARGIN 32
 #define MG_STAMP(slot)                                                     \
   do {                                                                    \
@@ -41,6 +44,11 @@ struct KArgs {
   const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
   const int* map_nasm;        // [P]
+  const int4* map_chest;      // [P][NCmax] (r, c, cfg, obj_id)
+  const int* map_nchest;      // [P]
+  DAgent* chests;             // [E][NCmax] chest records (inventory holders, same layout as agents)
+  const DAgent* t_chests;     // [P][NCmax] episode-start templates
+  int NCmax, TSC;             // chest slots per map; token-list stride of a chest
   const float* map_objcount;  // [P][n_cells]
   uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
@@ -98,6 +106,9 @@ struct Lds {
   int* tmp;  // [8][96] scratch ints: one slot per concurrently acting lane
   uint16_t* grid;
   DAgent* ag;
+  DAgent* ch;       // chest records (directly after the agent records)
+  int* gsetv;       // [16] pending chest.<r>.amount values; gsetm[0] = which
+  uint32_t* gsetm;
   DAsm* as;
   int* gd;
   uint32_t* dirty_amt;
@@ -127,7 +138,8 @@ __device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
 }
 
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
-                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1) {
+                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1,
+                                           int NC = 0) {
   if (a_rec < 0) a_rec = A;  // agent records staged in LDS (0: the kernel works on the records in HBM)
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -141,7 +153,8 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->dc = (int*)(base + dco);
     l->tmp = (int*)(base + tmpo);
   }
-  size_t g = take((size_t)HW * 2), ag = take((size_t)a_rec * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t gsv = take(16 * 4 + 16);
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
@@ -151,6 +164,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
+    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64);
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
     l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
@@ -161,7 +175,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
 
 // LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
 __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
-                                               int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1) {
+                                               int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1, int NC = 0) {
   if (a_rec < 0) a_rec = A;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -171,7 +185,7 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   };
   size_t dco = take((size_t)dcw * 4);
   if (l) l->dc = (int*)(base + dco);
-  size_t g = take((size_t)HW * 2), ag = take((size_t)a_rec * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take((size_t)NOBJ * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
   // the static assembler info is only read while the token lists are built, the row buffers only afterwards
@@ -181,6 +195,7 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
     l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
+    l->ch = l->ag + a_rec;
     l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
     l->rows = (uint8_t*)(base + rows);
   }
@@ -225,28 +240,34 @@ __device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, in
 }
 
 __device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
-  const CellCodec cc{a.NW, a.A};
+  const CellCodec cc{a.NW, a.A, a.NAmax};
   for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = cc.agent(i);
 }
 
 __device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
   return obj < a.NW ? obj * a.TSW
-                    : (obj < a.NW + a.A ? a.NW * a.TSW + (obj - a.NW) * a.TSA
-                                        : a.NW * a.TSW + a.A * a.TSA + (obj - a.NW - a.A) * a.TSS);
+                    : (obj < a.NW + a.A
+                           ? a.NW * a.TSW + (obj - a.NW) * a.TSA
+                           : (obj < a.NW + a.A + a.NAmax
+                                  ? a.NW * a.TSW + a.A * a.TSA + (obj - a.NW - a.A) * a.TSS
+                                  : a.NW * a.TSW + a.A * a.TSA + a.NAmax * a.TSS + (obj - a.NW - a.A - a.NAmax) * a.TSC));
 }
 
 // Build every object's token list once (they are observer independent) and the pattern table.
 // Requires l.ainfo (the map's static assembler info) staged + a barrier before.
 __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
   const int* dc = a.dc;
-  const CellCodec cc{a.NW, a.A};
+  const CellCodec cc{a.NW, a.A, a.NAmax};
   const int4* asm_info = l.ainfo;
   const int nasm = a.map_nasm[map_id];
+  const int nchest = a.NCmax > 0 ? a.map_nchest[map_id] : 0;
+  const int4* chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+  const int first_chest = a.NW + a.A + a.NAmax;
   for (int obj = tid; obj < a.NOBJ; obj += nt) {
     const int ho = mg_heap_off(a, obj);
     PairOut out{l.heap + ho, 0};
-    if (obj < a.NW + a.A + nasm)
-      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out);
+    if (obj < a.NW + a.A + nasm || (obj >= first_chest && obj < first_chest + nchest))
+      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
     l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
   }
   const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
@@ -551,6 +572,30 @@ __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e
     int oi = gr[GR_OFF_INITIAL], n = L_n(dc, oi);
     for (int k = 0; k < n; k++) inv_update(cx, i, KV_k(dc, oi, k), KV_v(dc, oi, k), true);
   }
+  // chests (chest.hpp:83-87): initial inventory, positive amounts only, limits ignored.  One thread, map order: the
+  // chest.<r>.amount game stat is a `set`, the last chest holding <r> wins.
+  if (tid == 0) {
+    *l.gsetm = 0;
+    const int nchest = a.NCmax > 0 ? a.map_nchest[map_id] : 0;
+    const int4* chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+    for (int ci = 0; ci < a.NCmax; ci++) {
+      DAgent rec;
+      memset(&rec, 0, sizeof(rec));
+      rec.nb = 1;
+      if (ci < nchest) {
+        const int4 info = chest_info[ci];
+        rec.r = rec.prev_r = (uint16_t)info.x;
+        rec.c = rec.prev_c = (uint16_t)info.y;
+        rec.group = (uint8_t)(dc + dc[dc[DC_OFF_CHESTS] + info.z])[CR_GROUP];
+      }
+      l.ch[ci] = rec;
+      if (ci < nchest) {
+        const int oi = group_rec(dc, rec.group)[GR_OFF_INITIAL], n = L_n(dc, oi);
+        for (int k = 0; k < n; k++)
+          if (KV_v(dc, oi, k) > 0) inv_update(cx, a.A + ci, KV_k(dc, oi, k), KV_v(dc, oi, k), true);
+      }
+    }
+  }
   __threadfence_block();
   __syncthreads();
 }
@@ -583,6 +628,11 @@ __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& c
       gs_[i] += (float)v;
       atomicOr(&gt_[i >> 5], 1u << (i & 31));
     }
+  }
+  if (a.NCmax > 0 && tid < a.R && ((*l.gsetm >> tid) & 1u)) {  // StatsTracker::set of chest.<r>.amount
+    const int s = cx.GS.chest_amount(tid);
+    gs_[s] = (float)l.gsetv[tid];
+    atomicOr(&gt_[s >> 5], 1u << (s & 31));
   }
 }
 
@@ -675,7 +725,13 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e,
   cx.asm_dirty = 0;
   cx.AS = MgAgentSlots{a.R, a.NG};
   cx.GS = MgGameSlots{a.R, a.n_cells - 1};
-  cx.cc = CellCodec{a.NW, a.A};
+  cx.cc = CellCodec{a.NW, a.A, a.NAmax};
+  cx.ch = l.ch;
+  cx.chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+  cx.NC = a.NCmax;
+  cx.gsetv = l.gsetv;
+  cx.gsetm = l.gsetm;
+  cx.overflow = 0;
 }
 
 // Cooperative copy of `bytes` (a multiple of 4) between HBM arrays: 16 bytes per lane and several loads in flight
@@ -778,6 +834,8 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
   env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
   mg_copy(a.agents + (size_t)e * a.A, a.t_agents + (size_t)m * a.A, (size_t)a.A * sizeof(DAgent), tid, nt);
   mg_copy(a.asms + (size_t)e * a.NAmax, a.t_asms + (size_t)m * a.NAmax, (size_t)a.NAmax * sizeof(DAsm), tid, nt);
+  if (a.NCmax > 0)
+    mg_copy(a.chests + (size_t)e * a.NCmax, a.t_chests + (size_t)m * a.NCmax, (size_t)a.NCmax * sizeof(DAgent), tid, nt);
   mg_copy(a.astats + (size_t)e * a.A * a.SA, a.t_astats + (size_t)m * a.A * a.SA, (size_t)a.A * a.SA * 4, tid, nt);
   mg_copy(a.atouched + (size_t)e * a.A * a.TW, a.t_atouched + (size_t)m * a.A * a.TW, (size_t)a.A * a.TW * 4, tid, nt);
   mg_copy(a.gstats + (size_t)e * a.SG, a.t_gstats + (size_t)m * a.SG, (size_t)a.SG * 4, tid, nt);
@@ -951,7 +1009,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
     inb = tr >= 0 && tc >= 0 && tr < H && tc < W;
     if (inb) scell = a.map_cells[(size_t)env.map_id * a.HW + tr * W + tc];
   }
-  const CellCodec cc{a.NW, A};
+  const CellCodec cc{a.NW, A, a.NAmax};
   const int skind = cc.kind(scell);
   const bool mover = is_move && inb && skind == MG_CELL_EMPTY;
   const bool user = is_move && inb && skind == MG_CELL_ASSEMBLER;
@@ -1230,7 +1288,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0);
+  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0, -1, a.NCmax);
   if (BIG) l.grid = a.big_grid + (size_t)e * a.HW;
   MG_STAMP(8);
   if (DCL) {
@@ -1252,7 +1310,13 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
   uint4* d2 = (uint4*)l.as;
   for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
-    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  {
+    const uint4* s3 = (const uint4*)(a.chests + (size_t)e * a.NCmax);
+    uint4* d3 = (uint4*)l.ch;
+    for (int i = tid; i < a.NCmax * (int)(sizeof(DAgent) / 16); i += nt) d3[i] = s3[i];
+    if (tid == 0) *l.gsetm = 0;
+  }
+  for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
   for (int i = tid; i < a.A; i += nt) {
     l.dirty_amt[i] = 0;
     l.dirty_misc[i] = 0;
@@ -1308,7 +1372,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
     if (dc[DC_HAS_DAMAGE])  // bindings/mettagrid_c.cpp:642-650: after regeneration, agent order
       for (int ai = 0; ai < a.A; ai++) mg_check_damage(cx, ai, rng);
     l.flags[0] = rng.used;
-    l.flags[1] = rng.overflow;
+    l.flags[1] = rng.overflow | (cx.overflow ? 8 : 0);
     l.flags[2] = cx.asm_dirty;
   }
   __syncthreads();
@@ -1323,6 +1387,11 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
       const uint4* s2 = (const uint4*)l.as;
       for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
     }
+    {
+      uint4* d3 = (uint4*)(a.chests + (size_t)e * a.NCmax);
+      const uint4* s3 = (const uint4*)l.ch;
+      for (int i = tid; i < a.NCmax * (int)(sizeof(DAgent) / 16); i += nt) d3[i] = s3[i];
+    }
     uint32_t new_idx = env.mt_idx + (uint32_t)l.flags[0];
     if (new_idx > 624) {  // == 624: the block is exhausted but untwisted; the next step twists it
       uint32_t* mt = a.mt + (size_t)e * 624;
@@ -1331,7 +1400,8 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
     }
     if (tid == 0) {
       env.mt_idx = new_idx;
-      if (l.flags[1]) env.error |= 1u;
+      if (l.flags[1] & 1) env.error |= 1u;
+      if (l.flags[1] & 8) env.error |= 8u;
       a.env[e] = env;
     }
   }
@@ -1343,15 +1413,16 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // BIG: grid tile and agent records are read in HBM (through L2); the token lists still live in LDS.
 template <bool DCL, bool BIG>
-__global__ __launch_bounds__(MG_THREADS, BIG ? 1 : 8) void mg_obs_kernel(KArgs a) {
+__global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
   mg_carve_obs(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
-               a.dc[DC_PATTERN_N], BIG ? 0 : a.A);
+               a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
     l.grid = a.big_grid + (size_t)e * a.HW;
     l.ag = a.agents + (size_t)e * a.A;
+    l.ch = a.chests + (size_t)e * a.NCmax;
   }
   if (DCL) {
     for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
@@ -1366,6 +1437,9 @@ __global__ __launch_bounds__(MG_THREADS, BIG ? 1 : 8) void mg_obs_kernel(KArgs a
       const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
       uint4* dst = (uint4*)l.ag;
       for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+      const uint4* s3 = (const uint4*)(a.chests + (size_t)e * a.NCmax);
+      uint4* d3 = (uint4*)l.ch;
+      for (int i = tid; i < a.NCmax * (int)(sizeof(DAgent) / 16); i += nt) d3[i] = s3[i];
     }
     const uint4* s2 = (const uint4*)(a.asms + (size_t)e * a.NAmax);
     uint4* d2 = (uint4*)l.as;
@@ -1408,10 +1482,11 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
   mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP,
-           a.dc[DC_PATTERN_N], BIG ? 0 : a.A);
+           a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
     l.grid = a.big_grid + (size_t)e * a.HW;
     l.ag = a.agents + (size_t)e * a.A;
+    l.ch = a.chests + (size_t)e * a.NCmax;
   }
   DEnv env = a.env[e];
   env.seed = a.reset_seeds[blockIdx.x];
@@ -1449,6 +1524,9 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
     uint4* dst = (uint4*)(a.agents + (size_t)e * a.A);
     const uint4* src = (const uint4*)l.ag;
     for (int i = tid; i < a.A * (int)(sizeof(DAgent) / 16); i += nt) dst[i] = src[i];
+    uint4* d3 = (uint4*)(a.chests + (size_t)e * a.NCmax);
+    const uint4* s3 = (const uint4*)l.ch;
+    for (int i = tid; i < a.NCmax * (int)(sizeof(DAgent) / 16); i += nt) d3[i] = s3[i];
   }
   uint4* d2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
   const uint4* s2 = (const uint4*)l.as;
@@ -1481,7 +1559,8 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   cx.tmp = nullptr;
   cx.dirty_amt = &dirty[0]; cx.dirty_misc = &dirty[1];
   cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
-  cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A};
+  cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A, a.NAmax};
+  cx.ch = nullptr; cx.chest_info = nullptr; cx.NC = 0; cx.gsetv = nullptr; cx.gsetm = nullptr; cx.overflow = 0;
   float* as_ = cx.astats;
   uint32_t* at_ = cx.atouched;
   uint8_t existing[MGD_MAX_R];
@@ -1548,6 +1627,7 @@ struct mg_handle {
   size_t ev_count = 0;         // steps recorded since profiling was enabled
   std::vector<std::vector<int4>> host_spawn, host_asm;  // per map (inspection)
   std::vector<int2> host_dims;                          // per map (height, width)
+  std::vector<std::vector<int4>> host_chest;            // per map (inspection)
   int* d_list = nullptr;       // scratch for reset lists [3][E]
   int* d_inv = nullptr;        // scratch for set_inventory [2][MGD_MAX_R]
   uint8_t* masks = nullptr;    // all ones (reference: mettagrid_c.cpp:983-995)
@@ -1584,13 +1664,11 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   }
   const MgConfig& c = h->cfg;
   if (c.R > MGD_MAX_R) return fail("mg_create: more than 16 resources are not supported on the device path yet");
-  if (!c.chests.empty()) return fail("mg_create: chest objects are not supported on the device path yet (SURVEY A19)");
   bool has_damage = false;
   for (const auto& g : c.groups)
     if (!g.damage_threshold.empty() && !g.damage_resources.empty()) has_damage = true;
   if (c.A > 8191) return fail("mg_create: too many agents per environment");
   for (const auto& a : c.assemblers) {
-    if (a.chest_search_distance > 0 && !c.chests.empty()) return fail("mg_create: chest search unsupported");
     for (const auto& p : a.protocols)
       if (p.vibes.size() > 8) return fail("mg_create: protocols with more than 8 vibes are not supported");
   }
@@ -1614,7 +1692,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   k.auto_reset = 1; k.map_stride = 1;
   {
     // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
-    bool ok = c.A <= 64 && c.regen_interval == 0 && !has_damage;
+    bool ok = c.A <= 64 && c.regen_interval == 0 && !has_damage && c.chests.empty();
     for (int v : c.vibe_handler) ok = ok && v == 0;
     for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
     const char* dg = getenv("MG_DIAG");
@@ -1701,10 +1779,11 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   HIPCHK(hipSetDevice(h->device));
   const MgConfig& c = h->cfg;
   KArgs& k = h->k;
-  const CellCodec codec{(int)c.walls.size(), c.A};
+  // (the assembler / chest slot counts are known only after the scan: codes are patched below)
+  CellCodec codec{(int)c.walls.size(), c.A, 0};
   std::vector<uint16_t> cells((size_t)num_maps * HWp, 0);
   std::vector<int4> spawn((size_t)num_maps * c.A);
-  std::vector<std::vector<int4>> asm_lists((size_t)num_maps);
+  std::vector<std::vector<int4>> asm_lists((size_t)num_maps), chest_lists((size_t)num_maps);
   std::vector<float> objcount((size_t)num_maps * c.cells.size(), 0.f);
   h->host_spawn.assign((size_t)num_maps, {});
   std::vector<int2> dims((size_t)num_maps);
@@ -1739,6 +1818,10 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
             asm_lists[(size_t)m].push_back(make_int4(r, cc, cell.idx, (int)id));
             objcount[(size_t)m * c.cells.size() + code] += 1.f;
             break;
+          case MG_CELL_CHEST:
+            chest_lists[(size_t)m].push_back(make_int4(r, cc, cell.idx, (int)id));  // cell code patched below
+            objcount[(size_t)m * c.cells.size() + code] += 1.f;
+            break;
           default:
             return fail("mg_set_maps: unsupported object kind in map");
         }
@@ -1757,6 +1840,22 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     for (size_t i = 0; i < asm_lists[(size_t)m].size(); i++) asm_flat[(size_t)m * NAmax + i] = asm_lists[(size_t)m][i];
   }
   h->host_asm = asm_lists;
+  int NCmax = 0;
+  for (auto& v : chest_lists) NCmax = std::max(NCmax, (int)v.size());
+  codec.NA = NAmax;
+  if ((size_t)c.walls.size() + c.A + NAmax + NCmax + 1 >= (size_t)MG_MAX_OBJECTS)
+    return fail("mg_set_maps: too many objects for uint16 cells");
+  std::vector<int4> chest_flat((size_t)num_maps * std::max(NCmax, 1), make_int4(0, 0, 0, 0));
+  std::vector<int> nchest((size_t)num_maps);
+  for (int m = 0; m < num_maps; m++) {
+    nchest[(size_t)m] = (int)chest_lists[(size_t)m].size();
+    for (size_t i = 0; i < chest_lists[(size_t)m].size(); i++) {
+      const int4 ci = chest_lists[(size_t)m][i];
+      chest_flat[(size_t)m * NCmax + i] = ci;
+      cells[(size_t)m * HWp + (size_t)ci.x * widths[m] + ci.y] = codec.chest((int)i);
+    }
+  }
+  h->host_chest = chest_lists;
   // LDS budget
   // token-list strides: the most tokens an object of each kind can show (wall.hpp:26-38, agent.cpp:187-213,
   // assembler.hpp:528-578)
@@ -1768,12 +1867,14 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
     TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
   }
-  if (TSW > 255 || TSA > 255 || TSS > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
-  TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time
-  const int NOBJ = (int)c.walls.size() + c.A + NAmax;
-  const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS;
+  int TSC = 1;
+  for (const auto& ch : c.chests) TSC = std::max(TSC, 1 + c.R * c.n_inv_tokens + (int)ch.tags.size());  // chest.hpp:124-146
+  if (TSW > 255 || TSA > 255 || TSS > 255 || TSC > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
+  TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3; TSC = (TSC + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time
+  const int NOBJ = (int)c.walls.size() + c.A + NAmax + NCmax;
+  const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS + NCmax * TSC;
   const int NP = c.obs_h * c.obs_w;
-  k.NW = (int)c.walls.size(); k.NOBJ = NOBJ; k.TSW = TSW; k.TSA = TSA; k.TSS = TSS; k.HEAP = HEAP;
+  k.NW = (int)c.walls.size(); k.NOBJ = NOBJ; k.TSW = TSW; k.TSA = TSA; k.TSS = TSS; k.TSC = TSC; k.NCmax = NCmax; k.HEAP = HEAP;
   {
     int mx = std::max(TSW, std::max(TSA, TSS));
     k.CB = 1;
@@ -1784,10 +1885,10 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   // env lives in HBM, and the observation / reset kernels read the agent records in HBM too.
   const size_t LDS_MAX = 160 * 1024;
   bool big = false;
-  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP);
+  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, -1, NCmax);
   if (lds > LDS_MAX) {
     big = true;
-    lds = mg_carve(nullptr, nullptr, 0, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, 0);
+    lds = mg_carve(nullptr, nullptr, 0, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, 0, NCmax);
     if (lds > LDS_MAX)
       return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   }
@@ -1804,6 +1905,13 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   if (dalloc(h, &d_nasm, nasm.size(), true)) return 1;
   if (dalloc(h, &d_obj, objcount.size(), true)) return 1;
   if (dalloc(h, &d_asms, (size_t)h->E * NAmax, true)) return 1;
+  int4* d_chest; int* d_nchest; DAgent* d_chests;
+  if (dalloc(h, &d_chest, chest_flat.size(), true)) return 1;
+  if (dalloc(h, &d_nchest, nchest.size(), true)) return 1;
+  if (dalloc(h, &d_chests, (size_t)h->E * std::max(NCmax, 1), true)) return 1;
+  HIPCHK(hipMemcpy(d_chest, chest_flat.data(), chest_flat.size() * sizeof(int4), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_nchest, nchest.data(), nchest.size() * 4, hipMemcpyHostToDevice));
+  k.map_chest = d_chest; k.map_nchest = d_nchest; k.chests = d_chests;
   HIPCHK(hipMemcpy(d_cells, cells.data(), cells.size() * 2, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_spawn, spawn.data(), spawn.size() * sizeof(int4), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_asm, asm_flat.data(), asm_flat.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -1824,12 +1932,12 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   h->dc_lds = !big && k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
   int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
-  h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs);
+  h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0, -1, NCmax);
+  h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX) {
     h->dc_lds = false;
-    h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0);
-    h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs);
+    h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0, -1, NCmax);
+    h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   }
   if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
@@ -1852,6 +1960,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   // ---- episode-start templates: run the reset kernel once per map into template buffers ------------------
   {
     const size_t P = (size_t)num_maps, PA = P * c.A;
+    DAgent* t_chests;
+    if (dalloc(h, &t_chests, P * (size_t)std::max(NCmax, 1), true)) return 1;
     DAgent* t_agents; DAsm* t_asms; float* t_astats; uint32_t* t_atouched; float* t_gstats; uint32_t* t_gtouched;
     if (dalloc(h, &t_agents, PA, true)) return 1;
     if (dalloc(h, &t_asms, P * NAmax, true)) return 1;
@@ -1872,6 +1982,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     kt.env = (DEnv*)talloc(P * sizeof(DEnv));
     kt.mt = (uint32_t*)talloc(P * 624 * 4);
     kt.mt_init = nullptr;
+    kt.chests = t_chests;
     kt.agents = t_agents; kt.asms = t_asms; kt.astats = t_astats; kt.atouched = t_atouched;
     kt.gstats = t_gstats; kt.gtouched = t_gtouched;
     kt.obs = (uint8_t*)talloc(PA * c.T * 3);
@@ -1902,6 +2013,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     }
     for (void* q : tmp) (void)hipFree(q);
     if (rc) return rc;
+    k.t_chests = t_chests;
     k.t_agents = t_agents; k.t_asms = t_asms; k.t_astats = t_astats; k.t_atouched = t_atouched;
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
@@ -2138,6 +2250,33 @@ int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream) {
     for (int q = 0; q < a.n_items && q < R; q++) {
       o[9 + 2 * q] = a.order[q];
       o[9 + 2 * q + 1] = a.amt[a.order[q]];
+    }
+  }
+  return 0;
+}
+
+int mg_chest_state(mg_handle* h, int env, int32_t* out, int max_chests, int32_t* n_chests, void* stream) {
+  if (!h || !n_chests) return fail("mg_chest_state: NULL argument");
+  if (env < 0 || env >= h->E) return fail("mg_chest_state: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  DEnv d;
+  HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  const auto& lst = h->host_chest[(size_t)d.map_id];
+  *n_chests = (int32_t)lst.size();
+  if (!out || lst.empty()) return 0;
+  std::vector<DAgent> ch((size_t)k.NCmax);
+  HIPCHK(hipMemcpy(ch.data(), k.chests + (size_t)env * k.NCmax, ch.size() * sizeof(DAgent), hipMemcpyDeviceToHost));
+  const int R = k.R, stride = 5 + 2 * R;
+  for (size_t i = 0; i < lst.size() && (int)i < max_chests; i++) {
+    const DAgent& a = ch[i];
+    int32_t* o = out + i * (size_t)stride;
+    o[0] = lst[i].x; o[1] = lst[i].y; o[2] = lst[i].z; o[3] = lst[i].w; o[4] = a.n_items;
+    for (int q = 0; q < 2 * R; q++) o[5 + q] = -1;
+    for (int q = 0; q < a.n_items && q < R; q++) {
+      o[5 + 2 * q] = a.order[q];
+      o[5 + 2 * q + 1] = a.amt[a.order[q]];
     }
   }
   return 0;

@@ -14,7 +14,7 @@ enum MgDc {
   DC_R = 0, DC_A, DC_OBS_W, DC_OBS_H, DC_T, DC_TOKEN_BASE, DC_MAX_STEPS, DC_TRUNCATES,
   DC_G_COMPLETION, DC_G_LAST_ACTION, DC_G_LAST_REWARD, DC_G_COMPASS, DC_G_GOAL, DC_PROTO_OBS,
   DC_REGEN_INTERVAL, DC_INIT_PASSES, DC_N_VIBES, DC_NG, DC_N_INV_TOKENS, DC_N_ACTIONS, DC_MAX_PRIORITY,
-  DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE, DC_HAS_DAMAGE,
+  DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE, DC_HAS_DAMAGE, DC_N_CHESTS,
   DC_OBS_WORDS,  // the stream's prefix that the observation kernel needs (action/attack/transfer tables come after it)
   DC_FID0,
   DC_OFF_FID_INV = DC_FID0 + MG_F_COUNT, DC_OFF_FID_IN, DC_OFF_FID_OUT, DC_OFF_ACTIONS,
@@ -22,7 +22,7 @@ enum MgDc {
   DC_OFF_VIBE_HANDLER = DC_OFF_HANDLERS + 6, DC_OFF_ATK_CONSUMED, DC_OFF_ATK_DEFENSE, DC_OFF_ATK_ARMOR,
   DC_OFF_ATK_WEAPON, DC_OFF_ATK_ACTOR, DC_OFF_ATK_TARGET, DC_OFF_ATK_LOOT, DC_OFF_ATK_VIBE_BONUS,
   DC_OFF_VIBE_RESOURCE, DC_OFF_XFER_REQUIRED, DC_OFF_XFER_EFFECTS, DC_OFF_GROUPS, DC_OFF_WALLS, DC_OFF_ASMS,
-  DC_OFF_PATTERN, DC_OFF_CELLS, DC_HEADER_WORDS
+  DC_OFF_PATTERN, DC_OFF_CELLS, DC_OFF_CHESTS, DC_HEADER_WORDS
 };
 // group record
 enum MgGr {
@@ -31,6 +31,9 @@ enum MgGr {
   GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_OFF_DMG_THRESHOLD, GR_OFF_DMG_RESOURCES, GR_WORDS
 };
 enum MgWr { WR_TYPE_ID = 0, WR_VIBE, WR_OFF_TAGS, WR_WORDS };
+// chest record: CR_GROUP = index of the pseudo group record (after the agent groups) that carries the chest's inventory
+// configuration in the GR_* layout; CR_OFF_XFER -> n, then n x (vibe, offset of the (item, delta) kv-list)
+enum MgCr { CR_TYPE_ID = 0, CR_VIBE, CR_OFF_TAGS, CR_GROUP, CR_OFF_XFER, CR_WORDS };
 enum MgAr {
   AR_TYPE_ID = 0, AR_VIBE, AR_ALLOW_PARTIAL, AR_MAX_USES, AR_CLIP_IMMUNE, AR_START_CLIPPED, AR_CHEST_DIST, AR_OFF_TAGS,
   AR_N_PROTOCOLS, AR_OFF_PTABLE, AR_N_KEYS, AR_OFF_KEYS, AR_SIMPLE_PO, AR_WORDS
@@ -109,30 +112,32 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
   { int o = b.put_list(c.fid_inv); H(DC_OFF_FID_INV) = o + 1; }
   { int o = b.put_list(c.fid_in); H(DC_OFF_FID_IN) = o + 1; }
   { int o = b.put_list(c.fid_out); H(DC_OFF_FID_OUT) = o + 1; }
-  // groups
+  // groups (+ one pseudo group per chest type: the same record layout carries the chest's inventory configuration,
+  // so every inventory routine works on agents and chests alike)
   {
     std::vector<int32_t> table;
-    for (const auto& g : c.groups) {
+    const MgGroup empty_group{};
+    auto put_group = [&](const MgGroup& g, const MgInventoryCfg& inv) {
       int32_t rec[GR_WORDS] = {0};
       rec[GR_GROUP_ID] = g.group_id; rec[GR_NAME_IDX] = g.group_name_idx; rec[GR_FREEZE_DURATION] = g.freeze_duration;
       rec[GR_INITIAL_VIBE] = g.initial_vibe; rec[GR_OFF_TAGS] = b.put_list(g.tags);
-      rec[GR_N_LIMITS] = (int32_t)g.inv.limits.size();
+      rec[GR_N_LIMITS] = (int32_t)inv.limits.size();
       std::vector<int32_t> lim;
-      for (const auto& l : g.inv.limits) {
+      for (const auto& l : inv.limits) {
         lim.push_back(l.base);
         lim.push_back(b.put_kv(l.modifiers));
       }
       { int o = b.reserve((int)lim.size()); for (size_t i = 0; i < lim.size(); i++) b.w[(size_t)o + i] = lim[i]; rec[GR_OFF_LIMITS] = o; }
       std::vector<int32_t> limit_of((size_t)std::max(c.R, 1), -1), modifier((size_t)std::max(c.R, 1), 0);
       bool has_mod = false;
-      for (const auto& kv : g.inv.limits_map_order) limit_of[(size_t)kv.k] = kv.v;
-      for (const auto& kv : g.inv.limits_map_order)
-        for (const auto& m : g.inv.limits[(size_t)kv.v].modifiers) { modifier[(size_t)m.k] = 1; has_mod = true; }
+      for (const auto& kv : inv.limits_map_order) limit_of[(size_t)kv.k] = kv.v;
+      for (const auto& kv : inv.limits_map_order)
+        for (const auto& m : inv.limits[(size_t)kv.v].modifiers) { modifier[(size_t)m.k] = 1; has_mod = true; }
       { int o = b.reserve((int)limit_of.size()); for (size_t i = 0; i < limit_of.size(); i++) b.w[(size_t)o + i] = limit_of[i]; rec[GR_OFF_LIMIT_OF] = o; }
       { int o = b.reserve((int)modifier.size()); for (size_t i = 0; i < modifier.size(); i++) b.w[(size_t)o + i] = modifier[i]; rec[GR_OFF_MODIFIER] = o; }
       rec[GR_HAS_MODIFIERS] = has_mod ? 1 : 0;
-      rec[GR_OFF_LIMITS_ORDER] = b.put_kv(g.inv.limits_map_order);
-      rec[GR_OFF_INITIAL] = b.put_kv(g.inv.initial);
+      rec[GR_OFF_LIMITS_ORDER] = b.put_kv(inv.limits_map_order);
+      rec[GR_OFF_INITIAL] = b.put_kv(inv.initial);
       {
         int o = b.reserve(1 + 5 * (int)g.stat_rewards.size());
         b.w[(size_t)o] = (int32_t)g.stat_rewards.size();
@@ -160,10 +165,32 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
       int o = b.reserve(GR_WORDS);
       for (int i = 0; i < GR_WORDS; i++) b.w[(size_t)o + (size_t)i] = rec[i];
       table.push_back(o);
-    }
+    };
+    for (const auto& g : c.groups) put_group(g, g.inv);
+    for (const auto& ch : c.chests) put_group(empty_group, ch.inv);
     int o = b.reserve((int)table.size());
     for (size_t i = 0; i < table.size(); i++) b.w[(size_t)o + i] = table[i];
     H(DC_OFF_GROUPS) = o;
+  }
+  {  // chests (chest.hpp:20-147)
+    std::vector<int32_t> table;
+    for (size_t ci = 0; ci < c.chests.size(); ci++) {
+      const auto& ch = c.chests[ci];
+      int ot = b.put_list(ch.tags);
+      std::vector<int32_t> xf;
+      for (const auto& v : ch.vibe_transfers) { xf.push_back(v.first); xf.push_back(b.put_kv(v.second)); }
+      int ox = b.reserve(1 + (int)xf.size());
+      b.w[(size_t)ox] = (int32_t)ch.vibe_transfers.size();
+      for (size_t i = 0; i < xf.size(); i++) b.w[(size_t)ox + 1 + i] = xf[i];
+      int o = b.reserve(CR_WORDS);
+      b.w[(size_t)o + CR_TYPE_ID] = ch.type_id; b.w[(size_t)o + CR_VIBE] = ch.vibe; b.w[(size_t)o + CR_OFF_TAGS] = ot;
+      b.w[(size_t)o + CR_GROUP] = (int32_t)(c.groups.size() + ci); b.w[(size_t)o + CR_OFF_XFER] = ox;
+      table.push_back(o);
+    }
+    int o = b.reserve((int)table.size());
+    for (size_t i = 0; i < table.size(); i++) b.w[(size_t)o + i] = table[i];
+    H(DC_OFF_CHESTS) = o;
+    H(DC_N_CHESTS) = (int32_t)c.chests.size();
   }
   {
     std::vector<int32_t> table;

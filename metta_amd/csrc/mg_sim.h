@@ -14,22 +14,27 @@
 #include "mg_device_cfg.h"
 
 // Grid cell encoding (uint16): 0 = empty, else 1 + object index in the env's unified object numbering
-//   [0, NW) wall types | [NW, NW + A) agents | [NW + A, NW + A + NA) assembler instances of the map.
+//   [0, NW) wall types | [NW, NW + A) agents | [NW + A, NW + A + NA) assembler instances of the map | chests.
 // Walls carry no per-instance state, so a wall cell names its *type*; the static layer of a map (walls,
 // assemblers) is shared by every environment that plays it, agents are overlaid per environment.
 #define MG_MAX_OBJECTS 65534
 struct CellCodec {
-  int NW, A;
+  int NW, A, NA;  // wall types, agents, assembler slots per map; chests follow the assemblers
   __host__ __device__ __forceinline__ int kind(uint16_t v) const {
     int o = (int)v - 1;
-    return v == 0 ? MG_CELL_EMPTY : (o < NW ? MG_CELL_WALL : (o < NW + A ? MG_CELL_AGENT : MG_CELL_ASSEMBLER));
+    return v == 0 ? MG_CELL_EMPTY
+                  : (o < NW ? MG_CELL_WALL
+                            : (o < NW + A ? MG_CELL_AGENT : (o < NW + A + NA ? MG_CELL_ASSEMBLER : MG_CELL_CHEST)));
   }
   __host__ __device__ __forceinline__ bool is_agent(uint16_t v) const { return (int)v > NW && (int)v <= NW + A; }
+  __host__ __device__ __forceinline__ bool is_chest(uint16_t v) const { return (int)v > NW + A + NA; }
   __host__ __device__ __forceinline__ int agent_idx(uint16_t v) const { return (int)v - 1 - NW; }
   __host__ __device__ __forceinline__ int asm_idx(uint16_t v) const { return (int)v - 1 - NW - A; }
+  __host__ __device__ __forceinline__ int chest_idx(uint16_t v) const { return (int)v - 1 - NW - A - NA; }
   __host__ __device__ __forceinline__ int wall_idx(uint16_t v) const { return (int)v - 1; }
   __host__ __device__ __forceinline__ uint16_t agent(int i) const { return (uint16_t)(1 + NW + i); }
   __host__ __device__ __forceinline__ uint16_t assembler(int i) const { return (uint16_t)(1 + NW + A + i); }
+  __host__ __device__ __forceinline__ uint16_t chest(int i) const { return (uint16_t)(1 + NW + A + NA + i); }
   __host__ __device__ __forceinline__ uint16_t wall(int t) const { return (uint16_t)(1 + t); }
 };
 
@@ -74,9 +79,17 @@ struct Ctx {
   int* gd;                            // [SG] game stat deltas of this step
   uint32_t* dirty_amt;                // [A] bit r: <r>.amount was set this step
   uint32_t* dirty_misc;               // [A] bit0 diversity, bit1 max_steps_without_motion
+  // Chests (chest.hpp): inventory holders like agents.  Holder index h < A is agent h, h >= A is chest h - A; a chest
+  // record is a DAgent whose `group` names the pseudo group carrying its inventory configuration.
+  DAgent* ch;
+  const int4* __restrict__ chest_info;  // per map: (r, c, cfg, obj_id)
+  int NC;
+  int* gsetv;                         // [R] pending StatsTracker::set of chest.<r>.amount (last writer wins) ...
+  uint32_t* gsetm;                    // ... and which of them are pending
   int H, W, A, NA, R, SA, SG, NG;
   uint32_t step;
   int asm_dirty;
+  int overflow;                       // a fixed-size work list was too small (more than 24 chests around an assembler)
   MgAgentSlots AS;
   MgGameSlots GS;
   CellCodec cc;
@@ -89,6 +102,8 @@ __device__ __forceinline__ void mg_stat_add(Ctx& cx, int ai, int slot, int delta
   atomicAdd(&cx.astats[ai * cx.SA + slot], (float)delta);
   atomicOr(&cx.atouched[ai * cx.TW + (slot >> 5)], 1u << (slot & 31));
 }
+
+__device__ __forceinline__ DAgent* mg_holder(const Ctx& cx, int h) { return h < cx.A ? &cx.ag[h] : &cx.ch[h - cx.A]; }
 
 // ---- small list helpers over the dcfg stream ----------------------------------------------------------------
 __device__ __forceinline__ int L_n(const int* dc, int off) { return dc[off]; }
@@ -191,6 +206,15 @@ __device__ inline int mg_free_space(const Ctx& cx, const DAgent* a, int item) {
 
 // Agent::on_inventory_change (agent.cpp:74-101)
 __device__ inline void mg_on_change(Ctx& cx, int ai, int item, int delta) {
+  if (ai >= cx.A) {  // Chest::on_inventory_change (chest.hpp:56-63): game stats
+    if (delta > 0)
+      atomicAdd(&cx.gd[cx.GS.chest_deposited(item)], delta);
+    else if (delta < 0)
+      atomicAdd(&cx.gd[cx.GS.chest_withdrawn(item)], -delta);
+    cx.gsetv[item] = (int)cx.ch[ai - cx.A].amt[item];
+    *cx.gsetm |= 1u << item;
+    return;
+  }
   DAgent* a = &cx.ag[ai];
   if (delta > 0)
     mg_stat_add(cx, ai, cx.AS.gained(item), delta);
@@ -214,7 +238,7 @@ __device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, boo
 // Inventory::enforce_all_limits (inventory.cpp:126-158); nesting bounded at depth 3.
 template <int D>
 __device__ void mg_enforce_limits(Ctx& cx, int ai) {
-  DAgent* a = &cx.ag[ai];
+  DAgent* a = mg_holder(cx, ai);
   const int* dc = cx.dc;
   const int* gr = group_rec(dc, a->group);
   int nl = gr[GR_N_LIMITS], oo = gr[GR_OFF_LIMITS_ORDER], no = L_n(dc, oo);
@@ -237,7 +261,7 @@ __device__ void mg_enforce_limits(Ctx& cx, int ai) {
 // Inventory::update (inventory.cpp:37-85)
 template <int D>
 __device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, bool ignore_limits) {
-  DAgent* a = &cx.ag[ai];
+  DAgent* a = mg_holder(cx, ai);
   const int* dc = cx.dc;
   const int* gr = group_rec(dc, a->group);
   int initial = a->amt[item];
@@ -266,7 +290,7 @@ __device__ inline int inv_update(Ctx& cx, int ai, int item, int delta, bool igno
   return mg_inv_update<0>(cx, ai, item, delta, ignore);
 }
 
-// HasInventory::shared_update (has_inventory.cpp:7-73) over the agent inventories list[0..n) (n <= 8).
+// HasInventory::shared_update (has_inventory.cpp:7-73) over the inventories (holder indices) list[0..n), n <= 32.
 // The reference's "inventories to consider" vectors are sub-sequences of the list in list order, so they are kept as
 // bitmasks over list positions.
 __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item, int delta) {
@@ -281,9 +305,9 @@ __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item
       int pos = __ffs(m) - 1, ai = list[pos];
       bool now;
       if (delta_remaining > 0)
-        now = mg_free_space(cx, &cx.ag[ai], item) <= per;
+        now = mg_free_space(cx, mg_holder(cx, ai), item) <= per;
       else
-        now = (int)cx.ag[ai].amt[item] <= -per;
+        now = (int)mg_holder(cx, ai)->amt[item] <= -per;
       if (now) {
         delta_remaining -= inv_update(cx, ai, item, per);
         num_remaining--;
@@ -303,6 +327,50 @@ __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item
     delta_remaining -= inv_update(cx, list[pos], item, d);
   }
   return delta - delta_remaining;
+}
+
+// HasInventory::transfer_resources (has_inventory.cpp:76-108) between two holders.
+__device__ inline int mg_transfer_resources(Ctx& cx, int src, int dst, int item, int delta, bool destroy_untransferred) {
+  if (delta <= 0) return 0;
+  int max_give = min((int)mg_holder(cx, src)->amt[item], delta);
+  int max_recv = mg_free_space(cx, mg_holder(cx, dst), item);
+  int amount = min(max_give, max_recv);
+  int loss = destroy_untransferred ? max_give : amount;
+  inv_update(cx, src, item, -loss);
+  inv_update(cx, dst, item, amount);
+  return amount;
+}
+
+// Chest::onUse (chest.hpp:31-54,103-122): the actor's vibe selects (item, delta) pairs; positive = deposit.
+__device__ inline bool mg_chest_use(Ctx& cx, int ai, int chest_idx) {
+  const int* dc = cx.dc;
+  const int* rec = dc + dc[dc[DC_OFF_CHESTS] + cx.chest_info[chest_idx].z];
+  const int ox = rec[CR_OFF_XFER], nx = dc[ox];
+  if (nx == 0) return false;
+  int deltas = -1;
+  const int vibe = cx.ag[ai].vibe;
+  for (int i = 0; i < nx; i++)
+    if (dc[ox + 1 + 2 * i] == vibe) deltas = dc[ox + 2 + 2 * i];
+  if (deltas < 0) return false;
+  bool any = false;
+  const int n = L_n(dc, deltas), h = cx.A + chest_idx;
+  for (int i = 0; i < n; i++) {
+    const int item = KV_k(dc, deltas, i), v = KV_v(dc, deltas, i);
+    if (v > 0) {
+      int t = mg_transfer_resources(cx, ai, h, item, v, true);
+      if (t > 0) {
+        any = true;
+        mg_stat_add(cx, ai, cx.AS.chest_deposited(item), t);
+      }
+    } else if (v < 0) {
+      int t = mg_transfer_resources(cx, h, ai, item, -v, true);
+      if (t > 0) {
+        any = true;
+        mg_stat_add(cx, ai, cx.AS.chest_withdrawn(item), t);
+      }
+    }
+  }
+  return any;
 }
 
 // ---- assembler ---------------------------------------------------------------------------------------------
@@ -372,8 +440,14 @@ __device__ inline int mg_kv_lookup(const int* dc, int off, int k) {
 
 // Assembler::onUse (assembler.hpp:455-526) given the surrounding agents `near[0..nn)` in the reference's order
 // (NW..SE ring rotated to start at the actor, assembler.hpp:48-92) and their vibes at the time of use.
+// `inputs[0..n_inputs)` = the holders the inputs are drawn from: the surrounding agents, then the chests within
+// `chest_search_distance` (assembler.hpp:100-122); null = the surrounding agents only.
 __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx, const int* near, const uint8_t* near_vibes,
-                                             int nn) {
+                                             int nn, const int* inputs = nullptr, int n_inputs = 0) {
+  if (!inputs) {
+    inputs = near;
+    n_inputs = nn;
+  }
   const int* dc = cx.dc;
   DAsm* as = &cx.as[asm_idx];
   int4 info = cx.asm_info[asm_idx];
@@ -430,7 +504,7 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
   // can_afford_protocol: uint16 totals (assembler.hpp:124-137)
   for (int i = 0; i < n_in; i++) {
     int total = 0;
-    for (int q = 0; q < nn; q++) total = (total + cx.ag[near[q]].amt[in_k[i]]) & 0xFFFF;
+    for (int q = 0; q < n_inputs; q++) total = (total + mg_holder(cx, inputs[q])->amt[in_k[i]]) & 0xFFFF;
     if (total < (in_v[i] & 0xFFFF)) return false;
   }
   // get_output_inventories (assembler.hpp:198-223)
@@ -474,7 +548,7 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
     }
     if (!ok && !as->clipped) return false;
   }
-  for (int i = 0; i < n_in; i++) mg_shared_update(cx, near, nn, in_k[i], -in_v[i]);
+  for (int i = 0; i < n_in; i++) mg_shared_update(cx, inputs, n_inputs, in_k[i], -in_v[i]);
   for (int i = 0; i < n_out; i++) {
     int distributed = mg_shared_update(cx, outs, no, out_k[i], out_v[i]);
     if (distributed > 0) atomicAdd(&cx.gd[cx.GS.assembler_created(out_k[i])], distributed);  // LDS; uses may run on several lanes
@@ -526,7 +600,22 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
       nn++;
     }
   }
-  return mg_assembler_use_core(cx, ai_actor, asm_idx, near, vibes, nn);
+  const int dist = cx.NC > 0 ? asm_rec(cx.dc, info.z)[AR_CHEST_DIST] : 0;
+  if (dist <= 0) return mg_assembler_use_core(cx, ai_actor, asm_idx, near, vibes, nn);
+  // chests within the search distance, row-major (assembler.hpp:100-122); the list lives behind the use scratch
+  int* inputs = cx.tmp + 96;
+  int n_inputs = 0;
+  for (int q = 0; q < nn; q++) inputs[n_inputs++] = near[q];
+  for (int dr = -dist; dr <= dist; dr++)
+    for (int dcl = -dist; dcl <= dist; dcl++) {
+      if (dr == 0 && dcl == 0) continue;
+      int rr = ar + dr, c2 = ac + dcl;
+      if (rr < 0 || c2 < 0 || rr >= cx.H || c2 >= cx.W) continue;
+      uint16_t cv = cx.grid[rr * cx.W + c2];
+      if (cx.cc.is_chest(cv) && n_inputs < 32) inputs[n_inputs++] = cx.A + cx.cc.chest_idx(cv);
+      else if (cx.cc.is_chest(cv)) cx.overflow = 1;
+    }
+  return mg_assembler_use_core(cx, ai_actor, asm_idx, near, vibes, nn, inputs, n_inputs);
 }
 
 // ---- attack / transfer (attack.hpp:93-253, transfer.hpp:72-150) ----------------------------------------------
@@ -691,6 +780,7 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
     return false;  // Agent::onUse (agent.cpp:179-185)
   }
   if (kind == MG_CELL_ASSEMBLER) return mg_assembler_use(cx, ai, cx.cc.asm_idx(target));
+  if (kind == MG_CELL_CHEST) return mg_chest_use(cx, ai, cx.cc.chest_idx(target));
   return false;  // walls are not Usable
 }
 
@@ -894,9 +984,24 @@ struct CountOut {
 // The tokens an object shows to any observer (wall.hpp:26-38, agent.cpp:187-213, assembler.hpp:528-578).  They do not
 // depend on who looks, so the observation kernel builds each object's list once per step.
 template <class OUT>
+__device__ inline void mg_inventory_tokens(const int* dc, const DAgent* a, OUT& out) {  // observation_encoder.hpp:165-180
+  const int base = dc[DC_TOKEN_BASE], nit = dc[DC_N_INV_TOKENS], ofi = dc[DC_OFF_FID_INV];
+  const int ni = a->n_items;
+  for (int i = 0; i < ni; i++) {
+    int item = a->order[i], amount = a->amt[item];
+    out.put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
+    unsigned rem = (unsigned)amount / (unsigned)base;
+    for (int p = 1; p < nit && rem > 0; p++) {
+      out.put(dc[ofi + item * nit + p], rem % (unsigned)base);
+      rem /= (unsigned)base;
+    }
+  }
+}
+
+template <class OUT>
 __device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
                                         const int4* asm_info, CellCodec cc, int H, int W, uint32_t step, uint16_t cv,
-                                        OUT& out) {
+                                        OUT& out, const DAgent* chests = nullptr, const int4* chest_info = nullptr) {
   int kind = cc.kind(cv);
   const int f_tag = dc[DC_FID0 + MG_F_TAG], f_vibe = dc[DC_FID0 + MG_F_VIBE];
   if (kind == MG_CELL_WALL) {
@@ -907,20 +1012,10 @@ __device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, con
   } else if (kind == MG_CELL_AGENT) {
     const DAgent* a = &ag[cc.agent_idx(cv)];
     const int* gr = group_rec(dc, a->group);
-    int base = dc[DC_TOKEN_BASE], nit = dc[DC_N_INV_TOKENS], ofi = dc[DC_OFF_FID_INV];
     out.put(dc[DC_FID0 + MG_F_GROUP], gr[GR_GROUP_ID]);
     out.put(dc[DC_FID0 + MG_F_FROZEN], a->frozen != 0 ? 1 : 0);
     if (a->vibe != 0) out.put(f_vibe, a->vibe);
-    int ni = a->n_items;
-    for (int i = 0; i < ni; i++) {  // observation_encoder.hpp:165-180
-      int item = a->order[i], amount = a->amt[item];
-      out.put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
-      unsigned rem = (unsigned)amount / (unsigned)base;
-      for (int p = 1; p < nit && rem > 0; p++) {
-        out.put(dc[ofi + item * nit + p], rem % (unsigned)base);
-        rem /= (unsigned)base;
-      }
-    }
+    mg_inventory_tokens(dc, a, out);
     int ot = gr[GR_OFF_TAGS], nt = L_n(dc, ot);
     for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
   } else if (kind == MG_CELL_ASSEMBLER) {
@@ -954,5 +1049,12 @@ __device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, con
     int ot = rec[AR_OFF_TAGS], nt = L_n(dc, ot);
     for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
     if (rec[AR_VIBE] != 0) out.put(f_vibe, rec[AR_VIBE]);
+  } else if (kind == MG_CELL_CHEST) {  // chest.hpp:124-146
+    int idx = cc.chest_idx(cv);
+    const int* rec = dc + dc[dc[DC_OFF_CHESTS] + chest_info[idx].z];
+    if (rec[CR_VIBE] != 0) out.put(f_vibe, rec[CR_VIBE]);
+    mg_inventory_tokens(dc, &chests[idx], out);
+    int ot = rec[CR_OFF_TAGS], nt = L_n(dc, ot);
+    for (int i = 0; i < nt; i++) out.put(f_tag, L_at(dc, ot, i));
   }
 }

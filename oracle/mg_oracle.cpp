@@ -1326,6 +1326,22 @@ void mgo_assembler_state(void* h, int32_t* out) {
     o[5] = (int32_t)a.cooldown_end; o[6] = (int32_t)a.cooldown_duration; o[7] = (int32_t)a.uses_count;
   }
 }
+int mgo_num_chests(void* h) { return (int)((Env*)h)->chests.size(); }
+// Per chest: r, c, cfg, obj_id, n_items, (item, amount) pairs in map order, -1 padded (stride 5 + 2R)
+void mgo_chest_state(void* h, int32_t* out) {
+  Env* e = (Env*)h;
+  int R = e->cfg.R, stride = 5 + 2 * R;
+  for (size_t i = 0; i < e->chests.size(); i++) {
+    const ChestInst& c = e->chests[i];
+    int32_t* o = out + i * (size_t)stride;
+    o[0] = c.r; o[1] = c.c; o[2] = c.cfg; o[3] = (int32_t)c.obj_id; o[4] = (int32_t)c.inv.items.order.size();
+    for (int k = 0; k < 2 * R; k++) o[5 + k] = -1;
+    for (size_t k = 0; k < c.inv.items.order.size() && (int)k < R; k++) {
+      o[5 + 2 * k] = c.inv.items.order[k];
+      o[5 + 2 * k + 1] = c.inv.items.get(c.inv.items.order[k]);
+    }
+  }
+}
 // Object-id grid [H][W] (0 = empty), ids as the reference assigns them (row-major creation order).
 void mgo_grid(void* h, int32_t* out) {
   Env* e = (Env*)h;

@@ -54,6 +54,8 @@ def lib() -> ct.CDLL:
     L.mgo_agent_state.argtypes = [vp, i32p]
     L.mgo_num_assemblers.argtypes = [vp]
     L.mgo_assembler_state.argtypes = [vp, i32p]
+    L.mgo_num_chests.argtypes = [vp]
+    L.mgo_chest_state.argtypes = [vp, i32p]
     L.mgo_grid.argtypes = [vp, i32p]
     L.mgo_set_inventory.argtypes = [vp, ct.c_int, ct.c_int, i32p, i32p]
     L.mgo_test_shuffle.argtypes = [ct.c_uint32, ct.c_int, ct.c_int, i32p, ct.POINTER(ct.c_uint32)]
@@ -120,6 +122,14 @@ class OracleEnv:
         if n:
             self.L.mgo_assembler_state(self.h, _p(out, ct.c_int32))
         return out
+
+    def chest_state(self) -> np.ndarray:
+        n = self.L.mgo_num_chests(self.h)
+        R = len(self.compiled.resource_names)
+        out = np.zeros((max(n, 1), 5 + 2 * R), dtype=np.int32)
+        if n:
+            self.L.mgo_chest_state(self.h, _p(out, ct.c_int32))
+        return out[:n]
 
     def grid(self) -> np.ndarray:
         out = np.zeros((self.H, self.W), dtype=np.int32)

@@ -4,7 +4,7 @@ Small crowded maps so that every interaction of the step path fires within a few
 attack (defense / armor / weapon / loot / freeze / swap with frozen agents), transfer, assembler protocols with
 vibes, min_agents, partial usage and max_uses, shared limits with modifiers, regeneration, initial inventories,
 compass / goal tokens, odd and even observation windows, tiny token budgets (dropped tokens) and token bases
-10/16/100/256.  `device_safe=True` leaves out chests (not on the device path yet).
+10/16/100/256.  `device_safe` is kept for callers; every feature generated here runs on the device path.
 """
 
 from __future__ import annotations
@@ -75,7 +75,7 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridC
             vibe=int(rs.choice([0, 0, 2])), tags=[f"asm{i}", "station"] if rs.randint(2) else [],
         )  # fmt: skip
     want_chest = bool(rs.randint(2))
-    if want_chest and not device_safe:
+    if want_chest:
         vt = {}
         for v in ["give", "take", "heart", "default"]:
             if rs.randint(2):

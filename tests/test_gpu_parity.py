@@ -54,6 +54,7 @@ def _compare_state(b, oras, t):
         hs, os_ = b.agent_state(e), o.agent_state()
         assert np.array_equal(hs, os_), f"step {t} env {e}: agent state\n{hs}\n{os_}"
         assert np.array_equal(b.assembler_state(e), o.assembler_state()), f"step {t} env {e}: assembler state"
+        assert np.array_equal(b.chest_state(e), o.chest_state()), f"step {t} env {e}: chest state\n{b.chest_state(e)}\n{o.chest_state()}"
         d = stats_equal(b.get_episode_stats(e), o.get_episode_stats(), ignore_invalid_variants=False)
         assert d is None, f"step {t} env {e}: stats differ: {d}"
         assert np.array_equal(
