@@ -99,6 +99,10 @@ int mg_episode_stats(mg_handle* h, int env, int last_finished, float* agent_valu
                      float* game_values, uint8_t* game_touched, void* stream);
 int mg_stat_slots(mg_handle* h, int* n_agent_slots, int* n_game_slots);
 
+/* `current_stat_reward` of every agent of `env` (Agent::current_stat_reward, agent.hpp:36; exposed by
+ * `grid_objects`, mettagrid_c.cpp:831): out f32[A]. */
+int mg_agent_stat_reward(mg_handle* h, int env, float* out, void* stream);
+
 /* Chests of `env` (the Chest entries of `MettaGrid::grid_objects`, mettagrid_c.cpp:754-918; chest.hpp:20-147), in
  * row-major map order: out i32[n][5 + 2R] = {r, c, chest config index, object id, n_items, (item, amount) pairs in the
  * inventory's iteration order, -1 padded}.  `*n_chests` receives the count; `out` may be NULL to query it. */

@@ -55,6 +55,7 @@ class MettaGridBatch:
 
         self._torch = torch
         self.L = native.load()
+        self.cfg = cfg
         self.compiled = compiled or compile_game(cfg, init_obs_passes=init_obs_passes)
         self.num_envs = int(num_envs)
         self.num_agents = self.compiled.num_agents
@@ -253,6 +254,84 @@ class MettaGridBatch:
         if n.value:
             native.check(self.L.mg_chest_state(self._h, env, _p(out, ct.c_int32), n.value, ct.byref(n), self._stream()))
         return out[: n.value]
+
+    def grid_objects(self, env: int, min_row: int = -1, max_row: int = -1, min_col: int = -1, max_col: int = -1,
+                     ignore_types: Sequence[str] = ()) -> dict:
+        """`MettaGrid::grid_objects` (BIND/mettagrid_c.cpp:754-918) of one environment: {object id: dict}.
+
+        Holds the identity, position, inventory and the agent / assembler / chest state fields of the reference's
+        dicts.  Not reproduced: the injected per-feature observation values (`tag`, `protocol_input:*`, ...) and the
+        assembler's protocol listings (`current_protocol_*`, `protocols`) -- they restate the configuration."""
+        c = self.compiled
+        game = self.cfg.game if hasattr(self.cfg, "game") else None
+        mid = self.env_info(env)["map_id"]
+        grid = self.map_pool[mid]
+        ast = self.agent_state(env)
+        asm = self.assembler_state(env)
+        chs = self.chest_state(env)
+        rew = np.zeros(self.num_agents, np.float32)
+        native.check(self.L.mg_agent_stat_reward(self._h, env, _p(rew, ct.c_float), self._stream()))
+        step = self.current_step(env)
+        groups = self.agent_groups(env)
+        use_bounds = min_row >= 0 and max_row >= 0 and min_col >= 0 and max_col >= 0
+        out: dict[int, dict] = {}
+        oid = 0
+        n_agent = n_asm = n_chest = 0
+        obj_cfg = {k: o for k, o in game.objects.items()} if game is not None else {}
+        agent_cfgs = game.agents if (game is not None and game.agents) else None
+        for r in range(grid.shape[0]):
+            for col in range(grid.shape[1]):
+                code = int(grid[r, col])
+                if code == 0:
+                    continue
+                oid += 1
+                kind = c.cell_kinds[code - 1]
+                tname = c.cell_type_names[code - 1]
+                d: dict = {"id": oid, "type_name": tname}
+                rr, cc = r, col
+                if kind == 2:  # agent
+                    i = n_agent
+                    n_agent += 1
+                    st = ast[i]
+                    rr, cc = int(st[0]), int(st[1])
+                    acfg = agent_cfgs[i] if agent_cfgs else (game.agent if game is not None else None)
+                    d["inventory"] = {int(st[9 + 2 * k]): int(st[10 + 2 * k]) for k in range(int(st[8]))}
+                    d.update(
+                        group_id=int(acfg.team_id) if acfg is not None else groups[i],
+                        group_name=c.group_names[groups[i]],
+                        is_frozen=bool(st[4] != 0),
+                        freeze_remaining=int(st[4]),
+                        freeze_duration=int(acfg.freeze_duration) if acfg is not None else 0,
+                        vibe=int(st[5]),
+                        agent_id=i,
+                        current_stat_reward=float(rew[i]),
+                        steps_without_motion=int(st[6]),
+                    )
+                elif kind == 3:  # assembler
+                    a = asm[n_asm]
+                    n_asm += 1
+                    ocfg = obj_cfg.get(tname)
+                    d.update(
+                        cooldown_remaining=max(0, int(np.uint32(a[5])) - step),
+                        cooldown_duration=int(np.uint32(a[6])),
+                        is_clipped=bool(a[4]),
+                        is_clip_immune=bool(getattr(ocfg, "clip_immune", False)),
+                        uses_count=int(np.uint32(a[7])),
+                        max_uses=int(getattr(ocfg, "max_uses", 0)),
+                        allow_partial_usage=bool(getattr(ocfg, "allow_partial_usage", False)),
+                    )
+                elif kind == 4:  # chest
+                    ch = chs[n_chest]
+                    n_chest += 1
+                    d["inventory"] = {int(ch[5 + 2 * k]): int(ch[6 + 2 * k]) for k in range(int(ch[4]))}
+                d["location"] = (cc, rr)
+                d["r"], d["c"] = rr, cc
+                if tname in ignore_types:
+                    continue
+                if use_bounds and (rr < min_row or rr >= max_row or cc < min_col or cc >= max_col):
+                    continue
+                out[oid] = d
+        return out
 
     def set_inventory(self, env: int, agent: int, inventory: dict[int, int]) -> None:
         keys = order_from_pydict(list(inventory.keys()))

@@ -93,6 +93,7 @@ class CompiledGame:
     cell_names: list[str]  # cell_names[code - 1]
     cell_kinds: list[int]
     cell_group: list[int]  # group index for agent cells, else -1
+    cell_type_names: list[str]  # reference `type_name` of the object a cell code creates ("agent" or the objects key)
     group_names: list[str]
     tag_names: list[str]
     object_type_names: list[str]
@@ -195,16 +196,18 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     cell_kinds: list[int] = []
     cell_idx: list[int] = []
     cell_group: list[int] = []
+    cell_type_names: list[str] = []
 
-    def add_cell(name: str, kind: int, idx: int, group: int = -1) -> None:
+    def add_cell(name: str, kind: int, idx: int, group: int = -1, type_name: str = "agent") -> None:
         if name in cell_names:  # later registration overwrites (dict semantics)
             k = cell_names.index(name)
-            cell_kinds[k], cell_idx[k], cell_group[k] = kind, idx, group
+            cell_kinds[k], cell_idx[k], cell_group[k], cell_type_names[k] = kind, idx, group, type_name
             return
         cell_names.append(name)
         cell_kinds.append(kind)
         cell_idx.append(idx)
         cell_group.append(group)
+        cell_type_names.append(type_name)
 
     for gi, team in enumerate(team_groups):
         add_cell("agent." + group_names[gi], CELL_AGENT, gi, gi)
@@ -219,13 +222,13 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     for key, o in game.objects.items():
         obj_keys.append(key)
         if isinstance(o, WallConfig):
-            add_cell(o.map_name or key, CELL_WALL, len(walls))
+            add_cell(o.map_name or key, CELL_WALL, len(walls), type_name=key)
             walls.append(o)
         elif isinstance(o, AssemblerConfig):
-            add_cell(o.map_name or key, CELL_ASSEMBLER, len(assemblers))
+            add_cell(o.map_name or key, CELL_ASSEMBLER, len(assemblers), type_name=key)
             assemblers.append(o)
         elif isinstance(o, ChestConfig):
-            add_cell(o.map_name or key, CELL_CHEST, len(chests))
+            add_cell(o.map_name or key, CELL_CHEST, len(chests), type_name=key)
             chests.append(o)
         else:
             raise ValueError(f"Unknown object type: {key}")
@@ -508,6 +511,7 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
         cell_names=cell_names,
         cell_kinds=cell_kinds,
         cell_group=cell_group,
+        cell_type_names=cell_type_names,
         group_names=group_names,
         tag_names=tag_names,
         object_type_names=object_type_names,

@@ -2255,6 +2255,18 @@ int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream) {
   return 0;
 }
 
+int mg_agent_stat_reward(mg_handle* h, int env, float* out, void* stream) {
+  if (!h || !out) return fail("mg_agent_stat_reward: NULL argument");
+  if (env < 0 || env >= h->E) return fail("mg_agent_stat_reward: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  std::vector<DAgent> ag((size_t)k.A);
+  HIPCHK(hipMemcpy(ag.data(), k.agents + (size_t)env * k.A, ag.size() * sizeof(DAgent), hipMemcpyDeviceToHost));
+  for (int i = 0; i < k.A; i++) out[i] = ag[(size_t)i].cur_reward;
+  return 0;
+}
+
 int mg_chest_state(mg_handle* h, int env, int32_t* out, int max_chests, int32_t* n_chests, void* stream) {
   if (!h || !n_chests) return fail("mg_chest_state: NULL argument");
   if (env < 0 || env >= h->E) return fail("mg_chest_state: environment id out of range");

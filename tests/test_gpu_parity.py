@@ -312,6 +312,18 @@ def test_vs_reference_core():
     for e, r in enumerate(refs):
         d = stats_equal(b.get_episode_stats(e), r.env.get_episode_stats())
         assert d is None, d
+        # grid_objects (mettagrid_c.cpp:754-918): every key our host side reproduces, for every object
+        ours, theirs = b.grid_objects(e), r.env.grid_objects()
+        assert set(ours) == set(int(k) for k in theirs)
+        for oid, od in ours.items():
+            td = theirs[oid]
+            for k, v in od.items():
+                tv = td[k]
+                tv = {int(a): int(q) for a, q in tv.items()} if isinstance(tv, dict) else tv
+                assert tv == v, f"env {e} object {oid} key {k}: {v} vs {tv}"
+        sub = b.grid_objects(e, 10, 30, 5, 40, ignore_types=["wall"])
+        ref_sub = r.env.grid_objects(10, 30, 5, 40, ["wall"])
+        assert set(sub) == set(int(k) for k in ref_sub)
     b.close()
 
 
