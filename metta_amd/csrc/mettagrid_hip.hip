@@ -213,8 +213,9 @@ __host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int
   size_t dco = take((size_t)dcw * 4), tmpo = take(8 * 96 * 4);
   size_t ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A * 2);
-  size_t fl = take(16), rows = take((size_t)A * 32);
+  size_t fl = take(16), rows = take((size_t)A * 32), ai = take((size_t)(NA > 0 ? NA : 1) * 16);
   if (l) {
+    l->ainfo = (int4*)(base + ai);
     l->dc = (int*)(base + dco); l->tmp = (int*)(base + tmpo);
     l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->gd = (int*)(base + gd);
     l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm); l->order = (uint16_t*)(base + ord);
@@ -864,9 +865,8 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
 //   2. a fixed-point over "did agent j's move succeed", whose dependencies only point to lower ranks
 //      (unique solution; converges in a few ballots' worth of iterations),
 //   3. assembler uses (moves into an assembler), collected in rank order with the neighbour ring as it stood at
-//      that moment, and executed by the general kernel on LDS-staged inventories.
-// Environments that need anything else this step (episode restart, a frozen agent, a rejected RNG draw) are handed
-// to the general kernel whole (mode 2).
+//      that moment, and executed by mg_uses_kernel on LDS-staged inventories.
+// Episode restarts (template copies) and the rare rejected RNG draw (serial redraw) are handled in place.
 // ------------------------------------------------------------------------------------------------------------
 #define MG_FAST_THREADS 64
 __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
@@ -874,24 +874,31 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   const int lane = threadIdx.x, e = blockIdx.x + a.env_base;
   const int A = a.A;
   const int* dc = a.dc;
-  DEnv env = a.env[e];
-  if (a.auto_reset && env.done) mg_restart_env(a, e, env, lane, 64);  // wave-uniform
-  mg_use_map(a, env.map_id);
-  const int H = a.H, W = a.W;
   const bool active = lane < A;
   const size_t g = (size_t)e * A + (active ? lane : 0);
   DAgent* rec = a.agents + g;
-  // agent fields this path touches
+  // Everything that depends on nothing but e is requested at once (env words, agent fields, action): one round
+  // trip instead of two.  A restart rewrites the records, so that rare case reads them again.
+  DEnv env = a.env[e];
   uint4 f0 = make_uint4(0, 0, 0, 0);
   uint32_t max_swm = 0, succ0 = 0, succ1 = 0, succ2 = 0, fail0 = 0, fail1 = 0, fail2 = 0;
   int act = 0;
-  if (active) {
-    f0 = *(const uint4*)rec;
-    max_swm = rec->max_swm;
-    succ0 = rec->succ[0]; succ1 = rec->succ[1]; succ2 = rec->succ[2];
-    fail0 = rec->fail[0]; fail1 = rec->fail[1]; fail2 = rec->fail[2];
-    act = a.actions[g];
+  auto load_agent = [&]() {
+    if (active) {
+      f0 = *(const uint4*)rec;
+      max_swm = rec->max_swm;
+      succ0 = rec->succ[0]; succ1 = rec->succ[1]; succ2 = rec->succ[2];
+      fail0 = rec->fail[0]; fail1 = rec->fail[1]; fail2 = rec->fail[2];
+    }
+  };
+  load_agent();
+  if (active) act = a.actions[g];
+  if (a.auto_reset && env.done) {  // wave-uniform
+    mg_restart_env(a, e, env, lane, 64);
+    load_agent();
   }
+  mg_use_map(a, env.map_id);
+  const int H = a.H, W = a.W;
   int r = (int)(f0.x & 0xFFFF), c = (int)(f0.x >> 16);
   int frozen = (int)(int16_t)(f0.z & 0xFFFF);
   uint32_t vibe = (f0.z >> 16) & 0xFF, group = f0.z >> 24, swm = f0.w;
@@ -1172,15 +1179,16 @@ template <bool DCL>
 __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = MG_USES_THREADS, e = blockIdx.x + a.env_base;
+  // the mode word and the env words depend on nothing but e: one round trip for both
   const uint32_t mode = a.mode[e];
+  const uint32_t step = a.env[e].step;  // already advanced by the fast kernel
+  const uint32_t map_id = a.env[e].map_id;
   if ((mode & 0xFF) != 1) return;
   const int count = (int)(mode >> 8);
   Lds l;
   mg_carve_uses(smem, &l, a.A, a.NAmax, a.SG, DCL ? a.dc_words : 0);
   MG_STAMP(8);
   // every staging load is independent of the others: issue them together, one barrier
-  const uint32_t step = a.env[e].step;  // already advanced by the fast kernel
-  const uint32_t map_id = a.env[e].map_id;
   {
     const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
     uint4* d1 = (uint4*)l.ag;
@@ -1191,6 +1199,8 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
     const uint4* __restrict__ s3 = (const uint4*)(a.pend + (size_t)e * a.A * 32);
     uint4* d3 = (uint4*)l.rows;
     for (int i = tid; i < count * 2; i += nt) d3[i] = s3[i];
+    const int4* __restrict__ s4 = a.map_asm + (size_t)map_id * a.NAmax;  // read by every use: keep it off the chain
+    for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = s4[i];
     if (DCL) {
       const uint4* __restrict__ s0 = (const uint4*)a.dc;
       uint4* d0 = (uint4*)l.dc;
@@ -1207,6 +1217,7 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   mg_use_map(a, map_id);
   mg_make_ctx(a, l, cx, e, (int)map_id, step);
   cx.grid = nullptr;
+  cx.asm_info = l.ainfo;
   __syncthreads();
   MG_STAMP(9);
   // Uses that share neither an agent nor the assembler commute, so they run on separate lanes; conflicting ones are

@@ -459,7 +459,9 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
   if (remaining > 0 && !partial) return false;
   unsigned long long pv = 0;
   for (int q = 0; q < nn && q < 8; q++) pv |= (unsigned long long)near_vibes[q] << (8 * q);
-  int po = mg_select_protocol(dc, info.z, pv, nn, as->clipped != 0);
+  // a lone protocol under key 0 that needs no agents is the current protocol whoever stands around (AR_SIMPLE_PO)
+  int po = (rec[AR_SIMPLE_PO] >= 0 && as->clipped == 0) ? rec[AR_SIMPLE_PO]
+                                                        : mg_select_protocol(dc, info.z, pv, nn, as->clipped != 0);
   if (po < 0) return false;
   // protocol_to_use as (item, amount) lists
   int* in_k = cx.tmp + 16; int* in_v = cx.tmp + 32; int* out_k = cx.tmp + 48; int* out_v = cx.tmp + 64;
