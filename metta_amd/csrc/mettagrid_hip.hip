@@ -347,7 +347,7 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
     int p = q * 64 + lane;
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
     if (p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && !(a.diag & 512)) {
-      uint16_t cv = l.grid[r * W + c];
+      uint16_t cv = l.grid[__mul24(r, W) + c];
       if (cv != 0) meta[q] = l.ocnt[(int)cv - 1];  // heap offset | token count << 16
     }
   }
@@ -435,6 +435,8 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
   // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
   // more than the whole rest of the row).
+  uint8_t* env_obs = a.obs + (size_t)e * a.A * (size_t)row_bytes;
+  const uint32_t env_phase = (uint32_t)(((size_t)e * a.A * (size_t)row_bytes) & 15);
   const bool pairs = write_global && (a.A & 1) == 0 && (row_bytes & 15) == 8;
   const int group = pairs ? 2 : 1;
   uint2 carry = make_uint2(0, 0);
@@ -442,8 +444,8 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
     for (int h = 0; h < group; h++) {
       const int ai = a0 + h;
       // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
-      const size_t goff = ((size_t)e * a.A + ai) * (size_t)row_bytes;
-      const int phase = (int)(goff & 15);
+      const uint32_t roff = (uint32_t)ai * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
+      const int phase = (int)((env_phase + roff) & 15u);
       uint8_t* row = rowbuf + phase;
       for (int i = lane; i < (a.ROWB >> 4); i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
@@ -454,24 +456,32 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {
-        uint8_t* gbase = a.obs + goff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
+        uint8_t* gbase = env_obs + roff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
         const int end = phase + row_bytes;
-        const int first = pairs ? 0 : phase;            // pairs, odd row: the chunk at 0 holds the even row's tail
-        const int last = pairs && h == 0 ? end - 8 : end;  // pairs, even row: the tail waits for the odd row
-        if (pairs && h == 0) carry = *(const uint2*)(rowbuf + end - 8);
-        for (int ch = lane; ch * 16 < last; ch += 64) {
-          const int b0 = ch * 16;
-          if (b0 >= first && b0 + 16 <= last) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (pairs) {
+          // odd row: the chunk at 0 holds the even row's tail; even row: the tail waits for the odd row.  Every
+          // chunk is full; rows of up to 1024 bytes leave in one store instruction.
+          const int nch = (h == 0 ? end - 8 : end) >> 4;
+          if (h == 0) carry = *(const uint2*)(rowbuf + end - 8);
+          for (int ch = lane; ch < nch; ch += 64) {
+            const uint4 v = *(const uint4*)(rowbuf + ch * 16);
             // streamed out, never re-read by the step kernels: keep it from displacing the map pool and records in L2
-            const uint4 v = *(const uint4*)(rowbuf + b0);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + b0));
-          } else {  // the row's ragged head / tail
-            const int lo = b0 < first ? first : b0, hi = b0 + 16 < last ? b0 + 16 : last;
-            if (((lo | hi) & 3) == 0) {
-              for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
-            } else {
-              for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + ch * 16));
+          }
+        } else {
+          for (int ch = lane; ch * 16 < end; ch += 64) {
+            const int b0 = ch * 16;
+            if (b0 >= phase && b0 + 16 <= end) {
+              const uint4 v = *(const uint4*)(rowbuf + b0);
+              __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + b0));
+            } else {  // the row's ragged head / tail
+              const int lo = b0 < phase ? phase : b0, hi = b0 + 16 < end ? b0 + 16 : end;
+              if (((lo | hi) & 3) == 0) {
+                for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
+              } else {
+                for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+              }
             }
           }
         }
