@@ -136,6 +136,10 @@ int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* ite
  * sum of game stat slots...}.  This is the vector the multi-GPU path all-reduces. */
 int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream);
 
+/* The same accumulator vector in place: f64[*n] in HBM, added to by the step kernels when an episode ends.  A
+ * multi-GPU caller all-reduces (a copy of) it on its own stream and zeroes it, without a host round trip. */
+int mg_summary_buffer(mg_handle* h, double** device_ptr, int32_t* n);
+
 /* Per-step kernel timing with HIP events recorded on the stream each step kernel is launched on (no host sync in
  * the step call).  mg_set_profiling(h, 1) starts recording (up to 4096 steps); mg_profile_read waits for the
  * recorded steps, writes their durations in milliseconds and restarts recording.  bench.py's roofline line.

@@ -346,6 +346,14 @@ class MettaGridBatch:
         native.check(self.L.mg_finished_summary(self._h, _p(out, ct.c_double), int(clear), self._stream()))
         return out
 
+    def summary_tensor(self):
+        """The finished-episode accumulator vector as a torch float64 tensor aliasing HBM (see finished_summary):
+        `s = t.clone(); t.zero_(); dist.all_reduce(s)` keeps the multi-GPU exchange on the stream."""
+        ptr, n = ct.POINTER(ct.c_double)(), ct.c_int32()
+        native.check(self.L.mg_summary_buffer(self._h, ct.byref(ptr), ct.byref(n)))
+        addr = ct.cast(ptr, ct.c_void_p).value
+        return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<f8", self), device=self.device)
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             self.L.mg_destroy(self._h)

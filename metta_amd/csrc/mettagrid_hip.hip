@@ -2372,6 +2372,13 @@ int mg_finished_summary(mg_handle* h, double* out, int clear, void* stream) {
   return 0;
 }
 
+int mg_summary_buffer(mg_handle* h, double** device_ptr, int32_t* n) {
+  if (!h || !device_ptr || !n) return fail("mg_summary_buffer: NULL argument");
+  *device_ptr = h->k.summary;
+  *n = 3 + h->k.SG;
+  return 0;
+}
+
 int mg_set_profiling(mg_handle* h, int enabled) {
   if (!h) return fail("mg_set_profiling: NULL handle");
   HIPCHK(hipSetDevice(h->device));
