@@ -337,7 +337,8 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
                                       int action, uint8_t* __restrict__ row, const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
   const DAgent* me = &l.ag[ai];
   const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
-  const int ar = me->r, ac = me->c;
+  const uint32_t rc = *(const uint32_t*)me;  // r | c << 16 (first two fields of the record)
+  const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
   // window lookups of all rounds first (independent LDS reads overlap).  Window offsets never exceed the radius, so
   // "inside the window and the map" is just "inside the map".
   uint32_t meta[NR];
@@ -439,6 +440,7 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   const uint32_t env_phase = (uint32_t)(((size_t)e * a.A * (size_t)row_bytes) & 15);
   const bool pairs = write_global && (a.A & 1) == 0 && (row_bytes & 15) == 8;
   const int group = pairs ? 2 : 1;
+  const int nfill = a.ROWB >> 4;
   uint2 carry = make_uint2(0, 0);
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group)
     for (int h = 0; h < group; h++) {
@@ -447,7 +449,11 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
       const uint32_t roff = (uint32_t)ai * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
       const int phase = (int)((env_phase + roff) & 15u);
       uint8_t* row = rowbuf + phase;
-      for (int i = lane; i < (a.ROWB >> 4); i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (nfill <= 64) {
+        if (lane < nfill) ((uint4*)rowbuf)[lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      } else {
+        for (int i = lane; i < nfill; i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      }
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
