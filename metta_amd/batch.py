@@ -153,6 +153,10 @@ class MettaGridBatch:
             t = torch.as_tensor(actions)
             if t.numel() != self.actions.numel():
                 raise RuntimeError("actions has the wrong shape")
+            # np.copyto(buffers.actions, actions, casting="safe") in MettaGridPufferEnv.step (mettagrid_puffer_env.py:
+            # 166-169) raises TypeError for anything that does not cast safely to int32
+            if t.dtype not in (torch.int32, torch.int16, torch.int8, torch.uint8):
+                raise TypeError(f"Cannot cast actions from {t.dtype} to int32 according to the rule 'safe'")
             self.actions.copy_(t.reshape(-1).to(dtype=torch.int32), non_blocking=True)
         native.check(self.L.mg_step(self._h, self._stream()))
 
@@ -345,6 +349,17 @@ class MettaGridBatch:
         out = np.zeros(3 + len(self.compiled.game_slot_names), np.float64)
         native.check(self.L.mg_finished_summary(self._h, _p(out, ct.c_double), int(clear), self._stream()))
         return out
+
+    def dlpack(self, name: str):
+        """DLPack capsule of one of the aliased buffers (`observations`, `rewards`, `terminals`, `truncations`,
+        `actions`, `masks`, `episode_rewards`, `action_success`): the zero-copy hand-over to any DLPack consumer.
+        The torch tensors of this object are themselves DLPack producers (`torch.from_dlpack(batch.rewards)`)."""
+        from torch.utils.dlpack import to_dlpack
+
+        t = getattr(self, name)
+        if not isinstance(t, self._torch.Tensor):
+            raise KeyError(name)
+        return to_dlpack(t)
 
     def summary_tensor(self):
         """The finished-episode accumulator vector as a torch float64 tensor aliasing HBM (see finished_summary):

@@ -187,6 +187,8 @@ class MettaGridDeviceVecEnv:
             if a.size != self.num_agents:
                 raise APIUsageError("Actions do not match action space")
             actions = torch.as_tensor(a.reshape(-1)).to(dtype=torch.int32)
+        elif actions.dtype != torch.int32 and not actions.dtype.is_floating_point:
+            actions = actions.to(torch.int32)  # the vecenv casts like pufferlib's send (vector.py), the env itself is strict
         b.step(actions.reshape(-1))
         self._steps += 1
         if self.stats_every == 1:

@@ -139,3 +139,28 @@ def test_training_environment_and_device_rollout():
     steps, secs, state, infos = rollout(env.vecenv, policy, 20)
     assert steps == 192 * 20 and state[0].shape == (192, 128)
     env.close()
+
+
+def test_buffers_dtype_errors_and_dlpack():
+    """reference tests/test_buffers.py:141-200: a dtype that does not cast safely is a TypeError, a wrong size a
+    RuntimeError; and the buffers leave through DLPack without a copy (BASELINE north_star)."""
+    import torch
+
+    from metta_amd.batch import MettaGridBatch
+
+    b = MettaGridBatch(make_arena(24), 2, load_map_pool()[:2], device=0, seeds=[1, 2], map_ids=[0, 1])
+    with pytest.raises(TypeError):
+        b.step(np.zeros(48, np.float32))
+    with pytest.raises(TypeError):
+        b.step(np.zeros(48, np.int64))
+    with pytest.raises(RuntimeError):
+        b.step(np.zeros(47, np.int32))
+    b.step(np.ones(48, np.int32))
+    b.step(torch.ones(48, dtype=torch.int32, device="cuda"))
+    assert b.current_step(0) == 2
+    for name in ("observations", "rewards", "terminals", "truncations", "actions", "masks", "episode_rewards"):
+        t = torch.from_dlpack(b.dlpack(name))
+        assert t.data_ptr() == getattr(b, name).data_ptr() and t.shape == getattr(b, name).shape
+    o = torch.from_dlpack(b.observations)  # the tensors are DLPack producers themselves
+    assert o.data_ptr() == b.observations.data_ptr()
+    b.close()
