@@ -87,6 +87,10 @@ def load() -> ct.CDLL:
             f"{_LIB_PATH} is missing: build it with `make -C metta_amd/csrc` (hipcc --offload-arch=gfx950). "
             "The device path has no CPU fallback."
         )
+    # torch ships its own libamdhip64: it must be the process's HIP runtime (tensors are exchanged by pointer), so
+    # it is loaded first and this library binds to the same one by soname
+    import torch  # noqa: F401
+
     L = ct.CDLL(str(_LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
