@@ -153,6 +153,19 @@ int mg_debug_stamps(mg_handle* h, unsigned long long* out, int enable);
 
 int mg_destroy(mg_handle* h);
 
+/* ---- rollout post-processing ------------------------------------------------------------------
+ * V-trace / GAE advantages over [num_rows][horizon] f32 device arrays (row-major, contiguous), on `stream`:
+ *   for t = horizon-2 .. 0:  nn = 1 - dones[t+1];  rho = min(importance[t], rho_clip);  c = min(importance[t], c_clip)
+ *                            delta = rho * (rewards[t+1] + gamma * values[t+1] * nn - values[t])
+ *                            advantages[t] = last = delta + gamma * lambda * c * last * nn
+ * advantages[horizon-1] is left as the caller set it.  Replaces `torch.ops.pufferlib.compute_puff_advantage`
+ * (packages/pufferlib-core/src/pufferlib/extensions/cuda/pufferlib.cu:7-86; CPU twin extensions/pufferlib.cpp:28-85),
+ * whose call site metta/rl/advantage.py:94-97 falls back to a Python loop on ROCm (metta/rl/mps.py:5-41).
+ * Bit-identical to the reference's CPU function (sequential per row, no fused multiply-add).  Needs no handle. */
+int mg_compute_advantage(const float* values, const float* rewards, const float* dones, const float* importance,
+                         float* advantages, float gamma, float lambda, float rho_clip, float c_clip, int num_rows,
+                         int horizon, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

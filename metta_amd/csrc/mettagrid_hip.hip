@@ -424,6 +424,8 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
 // Requires mg_build_tokens + a barrier before.
 __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                      bool write_global, int tid, int nt) {
+  // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
+  // moves to the scalar unit, SGPR spills go from 74 to 99 and the kernel gets slower, 62.5 us against 58.7)
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
   uint8_t* rowbuf = l.rows + (size_t)wave * a.ROWB;
   const int row_bytes = a.T * 3;
@@ -1194,6 +1196,9 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
 template <bool DCL>
 __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MG_ISA_LITE  // ISA inspection builds (tools/isa.sh): keep only the kernel under study
+  return;
+#endif
   const int tid = threadIdx.x, nt = MG_USES_THREADS, e = blockIdx.x + a.env_base;
   // the mode word and the env words depend on nothing but e: one round trip for both
   const uint32_t mode = a.mode[e];
@@ -1313,6 +1318,9 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
 template <bool DCL, bool BIG>
 __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MG_ISA_LITE  // ISA inspection builds (tools/isa.sh): keep only the kernel under study
+  return;
+#endif
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
   mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0, -1, a.NCmax);
@@ -1505,6 +1513,9 @@ __global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_ker
 template <bool BIG>
 __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MG_ISA_LITE  // ISA inspection builds (tools/isa.sh): keep only the kernel under study
+  return;
+#endif
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
@@ -1573,6 +1584,9 @@ __global__ void mg_end_episode_kernel(KArgs a, int env) {
 // Agent::set_inventory (agent.cpp:54-72) for one agent, on HBM state (single thread; inspection/test API).
 __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const int* items, const int* amounts) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MG_ISA_LITE  // ISA inspection builds (tools/isa.sh): keep only the kernel under study
+  return;
+#endif
   if (threadIdx.x != 0) return;
   DAgent* ag = (DAgent*)smem;
   uint32_t* dirty = (uint32_t*)(smem + mg_align16(sizeof(DAgent)));
@@ -1629,6 +1643,7 @@ static int fail(const std::string& m) {
   g_err = m;
   return 1;
 }
+int mg_fail_msg(const std::string& m) { return fail(m); }  // for the library's other translation units
 #define HIPCHK(x)                                                                                      \
   do {                                                                                                 \
     hipError_t _e = (x);                                                                               \

@@ -70,6 +70,10 @@ SYMBOLS = {
     "mg_profile_read": (ct.c_int, [_vp, _f32p, ct.c_int, ct.POINTER(ct.c_int)]),
     "mg_debug_stamps": (ct.c_int, [_vp, ct.POINTER(ct.c_uint64), ct.c_int]),
     "mg_destroy": (ct.c_int, [_vp]),
+    "mg_compute_advantage": (
+        ct.c_int,
+        [_vp, _vp, _vp, _vp, _vp, ct.c_float, ct.c_float, ct.c_float, ct.c_float, ct.c_int, ct.c_int, _vp],
+    ),
 }
 
 
