@@ -422,8 +422,9 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
 
 // All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
 // Requires mg_build_tokens + a barrier before.
-__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
-                                     bool write_global, int tid, int nt) {
+template <int NR, bool PAIRS>
+__device__ inline void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
+                                       bool write_global, int tid, int nt) {
   // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
   // moves to the scalar unit, SGPR spills go from 74 to 99 and the kernel gets slower, 62.5 us against 58.7)
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
@@ -433,15 +434,15 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
   const GlobalTok gt = mg_global_tok(a, step, lane);
   uint32_t pk[MG_MAX_ROUNDS];
 #pragma unroll
-  for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q * 64 + lane) < ec.P ? l.pat[q * 64 + lane] : 0u;
+  for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q < NR && (q * 64 + lane) < ec.P) ? l.pat[q * 64 + lane] : 0u;
   // Rows whose length is 8 mod 16 (T = 200: 600 bytes) alternate between phase 0 and 8 in HBM.  A wave then takes
   // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
   // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
   // more than the whole rest of the row).
   uint8_t* env_obs = a.obs + (size_t)e * a.A * (size_t)row_bytes;
   const uint32_t env_phase = (uint32_t)(((size_t)e * a.A * (size_t)row_bytes) & 15);
-  const bool pairs = write_global && (a.A & 1) == 0 && (row_bytes & 15) == 8;
-  const int group = pairs ? 2 : 1;
+  constexpr bool pairs = PAIRS;  // write_global && A even && row_bytes % 16 == 8 (checked by the caller)
+  constexpr int group = pairs ? 2 : 1;
   const int nfill = a.ROWB >> 4;
   uint2 carry = make_uint2(0, 0);
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group)
@@ -459,8 +460,7 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
-      int attempted = ec.P <= 128 ? mg_encode_agent<2>(a, l, ec, gt, ai, act, row, pk, lane)
-                                  : mg_encode_agent<MG_MAX_ROUNDS>(a, l, ec, gt, ai, act, row, pk, lane);
+      int attempted = mg_encode_agent<NR>(a, l, ec, gt, ai, act, row, pk, lane);
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {
@@ -496,6 +496,15 @@ __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32
       }
       __builtin_amdgcn_wave_barrier();
     }
+}
+
+// The headline shape (window of at most 128 cells, rows of 8 mod 16 bytes in pairs: 11 x 11 window, 200 tokens) has
+// a loop of its own, so that the general loop's state stays out of its registers.
+__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
+                                     bool write_global, int tid, int nt) {
+  const bool pairs = write_global && (a.A & 1) == 0 && ((a.T * 3) & 15) == 8 && a.ROWB <= 1024;
+  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true>(a, l, e, step, exec, write_global, tid, nt);
+  else mg_encode_all_t<MG_MAX_ROUNDS, false>(a, l, e, step, exec, write_global, tid, nt);  // any shape
 }
 
 // Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
@@ -911,7 +920,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   };
   load_agent();
   if (active) act = a.actions[g];
-  if (a.auto_reset && env.done) {  // wave-uniform
+  if (a.auto_reset && env.done && !(a.diag & 2048)) {  // wave-uniform (2048: timing ablation, wrong results)
     mg_restart_env(a, e, env, lane, 64);
     load_agent();
   }
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   // ---- MT19937 window -------------------------------------------------------------------
   const uint32_t* mt = a.mt + (size_t)e * 624;
   const int NW_ = a.NWIN < 64 ? a.NWIN : 64;
-  const bool need_twist = (int)env.mt_idx + NW_ > 624;
+  const bool need_twist = (int)env.mt_idx + NW_ > 624 && !(a.diag & 1024);  // 1024: timing ablation, wrong results
   if (need_twist) {
     for (int i = lane; i < 227; i += 64) mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
     __syncthreads();
@@ -1496,17 +1505,28 @@ __global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_ker
   __syncthreads();
   MG_STAMP(4);
   if (a.diag & 64) return;
+  // The closing phases read their pointers from the kernel-argument segment again (an opaque pointer, so that the
+  // loads are not merged with the ones at kernel entry): otherwise some thirty SGPRs stay live across the encode
+  // loop for their sake and are spilled there.
+  KArgs b = a;
+#if defined(__HIP_DEVICE_COMPILE__)
+  {
+    const __attribute__((address_space(4))) KArgs* ka =
+        (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    b = *ka;
+  }
+#endif
+  b.dc = a.dc; b.H = a.H; b.W = a.W;
   if (tid == 0) {
-    mg_token_stats(a, l, 1);
-    float* gs_ = a.gstats + (size_t)e * a.SG;
+    mg_token_stats(b, l, 1);
+    float* gs_ = b.gstats + (size_t)e * b.SG;
     gs_[0] = l.tokacc[0];
     gs_[1] = l.tokacc[1];
     gs_[2] = l.tokacc[2];
   }
   __syncthreads();
-  MG_STAMP(5);
-  mg_rewards_and_flags(a, l, e, env, tid, nt);
-  MG_STAMP(6);
+  mg_rewards_and_flags(b, l, e, env, tid, nt);
 }
 
 // Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.

@@ -2,7 +2,7 @@
 """Throughput of BASELINE configs[2] and [3] (informational; bench.py stays on configs[1]).
 
   python3 tools/bench_configs.py navigation   # 8192 envs x 4 agents, 64 maps of mixed sizes (60..120)^2
-  python3 tools/bench_configs.py combat       # 64 envs x 1024 agents on 256 x 256 maps (grid tiles in HBM)
+  python3 tools/bench_configs.py combat [steps] [envs]  # 64 (default) envs x 1024 agents on 256 x 256 maps (grid tiles in HBM)
   python3 tools/bench_configs.py rollout      # configs[4] on one GPU: 4096 arena envs x 24 agents + LSTM policy (bf16)
 """
 import json
@@ -36,7 +36,7 @@ def main():
             maps.append(mb.build(np.random.default_rng(i)))
         n_act = 5
     else:
-        A, E = 1024, 64
+        A, E = 1024, int(sys.argv[3]) if len(sys.argv) > 3 else 64
         cfg = make_combat_stress(A, 256)
         maps = [cfg.game.map_builder.build(np.random.default_rng(i)) for i in range(4)]
         n_act = 8
