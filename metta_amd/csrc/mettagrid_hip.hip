@@ -121,7 +121,7 @@ struct Lds {
   float* tokacc;  // [3] tokens_written / dropped / free_space accumulators
   int* flags;     // [4]
   uint8_t* rows;
-  uint32_t* ocnt;   // [NOBJ] per object this step: heap offset | token count << 16
+  uint32_t* ocnt;   // [-1 .. NOBJ) per object this step: heap offset | token count << 16; ocnt[-1] = 0 (the empty cell)
   uint16_t* heap;   // token lists (feature | value << 8): [NW][TSW] walls, [A][TSA] agents, [NA][TSS] assemblers
   int4* ainfo;      // [NA] static assembler info of the map (r, c, cfg, object id)
   uint32_t* pat;    // [P] (dr+8) | (dc+8) << 8 | location byte << 16
@@ -158,10 +158,10 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
-  size_t oc = take(nwaves ? (size_t)NOBJ * 4 : 0), hp = take(nwaves ? (size_t)HEAP * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
+  size_t oc = take(nwaves ? (size_t)(NOBJ + 1) * 4 : 0), hp = take(nwaves ? (size_t)HEAP * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
   size_t ai = take(nwaves ? (size_t)(NA > 0 ? NA : 1) * 16 : 0);
   if (l) {
-    l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64);
@@ -187,12 +187,12 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   if (l) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
-  size_t oc = take((size_t)NOBJ * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
+  size_t oc = take((size_t)(NOBJ + 1) * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
   // the static assembler info is only read while the token lists are built, the row buffers only afterwards
   size_t ai = rows;
   if ((size_t)(NA > 0 ? NA : 1) * 16 > (size_t)ROWB * nwaves) ai = take((size_t)(NA > 0 ? NA : 1) * 16);
   if (l) {
-    l->ocnt = (uint32_t*)(base + oc); l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
     l->ch = l->ag + a_rec;
@@ -271,6 +271,7 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
       mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
     l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
   }
+  if (tid == 0) l.ocnt[-1] = 0;  // cell code 0 (empty) looks up "no tokens" without a branch
   const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
   for (int p = tid; p < P; p += nt) {
     uint32_t packed = (uint32_t)dc[op + p];
@@ -332,10 +333,10 @@ __device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lan
 
 // One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
 // MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
-template <int NR>
-__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt, int ai,
-                                      int action, uint8_t* __restrict__ row, const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
-  const DAgent* me = &l.ag[ai];
+template <int NR, bool HOT = false>
+__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
+                                      const DAgent* me, int action, uint8_t* __restrict__ row,
+                                      const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
   const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
   const uint32_t rc = *(const uint32_t*)me;  // r | c << 16 (first two fields of the record)
   const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
@@ -347,10 +348,10 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
     meta[q] = 0;
     int p = q * 64 + lane;
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
-    if (p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && !(a.diag & 512)) {
-      uint16_t cv = l.grid[__mul24(r, W) + c];
-      if (cv != 0) meta[q] = l.ocnt[(int)cv - 1];  // heap offset | token count << 16
-    }
+    const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && (HOT || !(a.diag & 512));
+    // no branches: cells outside the map read cell 0 and are masked; empty cells read the zero entry ocnt[-1]
+    const uint32_t cv = l.grid[ok ? __mul24(r, W) + c : 0];
+    meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];  // heap offset | token count << 16
   }
   // Global tokens at the centre.  The fixed ones (episode completion, last action, last reward) sit one per lane,
   // prepared once per wave (GlobalTok); goal and compass tokens depend on the agent and follow from lane 0.
@@ -387,32 +388,41 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
 #pragma unroll
   for (int q = 0; q < NR; q++) {
     const int cnt = (int)(meta[q] >> 16);
-    // exclusive prefix sum of cnt over the wave: ones via mbcnt, the few multi-token objects by a uniform loop
-    unsigned long long any = __ballot(cnt > 0);
-    unsigned long long big = __ballot(cnt > 1);
-    int off = __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0));
-    int total = __popcll(any);
-    while (big) {
-      int j = __ffsll((long long)big) - 1;
-      big &= big - 1;
-      int cj = __builtin_amdgcn_readlane(cnt, j) - 1;
-      total += cj;
-      if (lane > j) off += cj;
+    // exclusive prefix sum of cnt over the wave: six DPP steps (row shifts, then the row broadcasts).  (A ballot +
+    // mbcnt count of the single-token objects plus a uniform loop over the multi-token ones cost 4 us more per launch.)
+    int off, total;
+    {
+      int x = cnt;
+      x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+      x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+      x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+      x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+      x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+      x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+      off = x - cnt;
+      total = __builtin_amdgcn_readlane(x, 63);
     }
     off += base;
-    if (cnt > 0 && off < T && !(a.diag & 128)) {
+    if (cnt > 0 && off < T && (HOT || !(a.diag & 128))) {
       // token lists start 8-byte aligned and are padded to x4 tokens: read 4 tokens per LDS access
       const uint2* __restrict__ src = (const uint2*)(l.heap + (meta[q] & 0xFFFF));
       const uint8_t loc = (uint8_t)(pk[q] >> 16);
       const int n = min(cnt, T - off);
       uint8_t* __restrict__ dst = row + off * 3;
-      for (int k = 0; k < n; k += 4) {
-        uint2 v = src[k >> 2];
-        uint32_t t0 = v.x & 0xFFFF, t1 = v.x >> 16, t2 = v.y & 0xFFFF, t3 = v.y >> 16;
-        dst[k * 3 + 0] = loc; dst[k * 3 + 1] = (uint8_t)t0; dst[k * 3 + 2] = (uint8_t)(t0 >> 8);
-        if (k + 1 < n) { dst[k * 3 + 3] = loc; dst[k * 3 + 4] = (uint8_t)t1; dst[k * 3 + 5] = (uint8_t)(t1 >> 8); }
-        if (k + 2 < n) { dst[k * 3 + 6] = loc; dst[k * 3 + 7] = (uint8_t)t2; dst[k * 3 + 8] = (uint8_t)(t2 >> 8); }
-        if (k + 3 < n) { dst[k * 3 + 9] = loc; dst[k * 3 + 10] = (uint8_t)t3; dst[k * 3 + 11] = (uint8_t)(t3 >> 8); }
+      uint2 v = src[0];
+      {  // most objects (walls) have one token: it goes out without any further test
+        const uint32_t t0 = v.x & 0xFFFF;
+        dst[0] = loc; dst[1] = (uint8_t)t0; dst[2] = (uint8_t)(t0 >> 8);
+      }
+      if (n > 1) {
+        for (int k = 0; k < n; k += 4) {
+          if (k) v = src[k >> 2];
+          uint32_t t0 = v.x & 0xFFFF, t1 = v.x >> 16, t2 = v.y & 0xFFFF, t3 = v.y >> 16;
+          if (k) { dst[k * 3 + 0] = loc; dst[k * 3 + 1] = (uint8_t)t0; dst[k * 3 + 2] = (uint8_t)(t0 >> 8); }
+          if (k + 1 < n) { dst[k * 3 + 3] = loc; dst[k * 3 + 4] = (uint8_t)t1; dst[k * 3 + 5] = (uint8_t)(t1 >> 8); }
+          if (k + 2 < n) { dst[k * 3 + 6] = loc; dst[k * 3 + 7] = (uint8_t)t2; dst[k * 3 + 8] = (uint8_t)(t2 >> 8); }
+          if (k + 3 < n) { dst[k * 3 + 9] = loc; dst[k * 3 + 10] = (uint8_t)t3; dst[k * 3 + 11] = (uint8_t)(t3 >> 8); }
+        }
       }
     }
     base += total;
@@ -445,14 +455,20 @@ __device__ inline void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint
   constexpr int group = pairs ? 2 : 1;
   const int nfill = a.ROWB >> 4;
   uint2 carry = make_uint2(0, 0);
-  for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group)
+  // per-agent offsets are carried along instead of multiplied out (v_mul_lo_u32 runs at quarter rate)
+  uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
+  const DAgent* me0 = l.ag + wave * group;
+  const uint32_t roff_step = (uint32_t)(nwaves * group) * (uint32_t)row_bytes;
+  for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
+#pragma unroll
     for (int h = 0; h < group; h++) {
       const int ai = a0 + h;
       // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
-      const uint32_t roff = (uint32_t)ai * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
-      const int phase = (int)((env_phase + roff) & 15u);
+      const uint32_t roff = roff0 + (uint32_t)(h * row_bytes);
+      // paired rows: A * row_bytes is a multiple of 16, the even row starts a chunk, the odd one sits at 8
+      const int phase = PAIRS ? h * 8 : (int)((env_phase + roff) & 15u);
       uint8_t* row = rowbuf + phase;
-      if (nfill <= 64) {
+      if (PAIRS || nfill <= 64) {  // the paired shape is only chosen for rows of at most 1024 bytes
         if (lane < nfill) ((uint4*)rowbuf)[lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
       } else {
         for (int i = lane; i < nfill; i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -460,7 +476,7 @@ __device__ inline void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
-      int attempted = mg_encode_agent<NR>(a, l, ec, gt, ai, act, row, pk, lane);
+      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, pk, lane);
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {
@@ -469,13 +485,15 @@ __device__ inline void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         if (pairs) {
           // odd row: the chunk at 0 holds the even row's tail; even row: the tail waits for the odd row.  Every
-          // chunk is full; rows of up to 1024 bytes leave in one store instruction.
+          // chunk is full; the rows (at most 1024 bytes in this shape) leave in one store instruction, addressed as
+          // uniform base + 32-bit lane offset.
           const int nch = (h == 0 ? end - 8 : end) >> 4;
           if (h == 0) carry = *(const uint2*)(rowbuf + end - 8);
-          for (int ch = lane; ch < nch; ch += 64) {
-            const uint4 v = *(const uint4*)(rowbuf + ch * 16);
+          if (lane < nch) {
+            const uint4 v = *(const uint4*)(rowbuf + lane * 16);
+            const uint32_t off32 = roff - (uint32_t)phase + (uint32_t)lane * 16u;
             // streamed out, never re-read by the step kernels: keep it from displacing the map pool and records in L2
-            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + ch * 16));
+            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(env_obs + off32));
           }
         } else {
           for (int ch = lane; ch * 16 < end; ch += 64) {

@@ -7,9 +7,11 @@ it raises.  The CPU restatement under oracle/ is test infrastructure and is neve
 from __future__ import annotations
 
 import ctypes as ct
+import os
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "libmettagrid_hip.so"
+# METTA_AMD_LIB: another build of the same library (kernel experiments, tools/variants.sh)
+_LIB_PATH = Path(os.environ.get("METTA_AMD_LIB") or Path(__file__).resolve().parent / "libmettagrid_hip.so")
 _lib = None
 
 
