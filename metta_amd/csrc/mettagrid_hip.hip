@@ -137,6 +137,9 @@ __device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
   a.W = d.y;
 }
 
+// FILL = false: sizes only (host).  A compile-time switch rather than `if (l)`: a null test on the kernel's Lds
+// object can survive to the back end and then keeps the whole struct in scratch memory (every LDS access turns flat).
+template <bool FILL>
 __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
                                            int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1,
                                            int NC = 0) {
@@ -149,7 +152,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   };
   size_t dco = take((size_t)dcw * 4);
   size_t tmpo = take(8 * 96 * 4);
-  if (l) {
+  if (FILL) {
     l->dc = (int*)(base + dco);
     l->tmp = (int*)(base + tmpo);
   }
@@ -160,7 +163,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take(nwaves ? (size_t)(NOBJ + 1) * 4 : 0), hp = take(nwaves ? (size_t)HEAP * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
   size_t ai = take(nwaves ? (size_t)(NA > 0 ? NA : 1) * 16 : 0);
-  if (l) {
+  if (FILL) {
     l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
@@ -174,6 +177,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
 }
 
 // LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
+template <bool FILL>
 __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
                                                int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1, int NC = 0) {
   if (a_rec < 0) a_rec = A;
@@ -184,14 +188,14 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
     return at;
   };
   size_t dco = take((size_t)dcw * 4);
-  if (l) l->dc = (int*)(base + dco);
+  if (FILL) l->dc = (int*)(base + dco);
   size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take((size_t)(NOBJ + 1) * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
   // the static assembler info is only read while the token lists are built, the row buffers only afterwards
   size_t ai = rows;
   if ((size_t)(NA > 0 ? NA : 1) * 16 > (size_t)ROWB * nwaves) ai = take((size_t)(NA > 0 ? NA : 1) * 16);
-  if (l) {
+  if (FILL) {
     l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
@@ -203,6 +207,7 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
 }
 
 // LDS of the assembler-use kernel (fast mode): config stream, records, stat deltas, the hand-over records.
+template <bool FILL>
 __host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int A, int NA, int SG, int dcw) {
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -214,7 +219,7 @@ __host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int
   size_t ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A * 2);
   size_t fl = take(16), rows = take((size_t)A * 32), ai = take((size_t)(NA > 0 ? NA : 1) * 16);
-  if (l) {
+  if (FILL) {
     l->ainfo = (int4*)(base + ai);
     l->dc = (int*)(base + dco); l->tmp = (int*)(base + tmpo);
     l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->gd = (int*)(base + gd);
@@ -334,7 +339,7 @@ __device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lan
 // One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
 // MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
 template <int NR, bool HOT = false>
-__device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
+__device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
                                       const DAgent* me, int action, uint8_t* __restrict__ row,
                                       const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
   const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
@@ -433,7 +438,7 @@ __device__ inline int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg
 // All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
 // Requires mg_build_tokens + a barrier before.
 template <int NR, bool PAIRS>
-__device__ inline void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
+__device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                        bool write_global, int tid, int nt) {
   // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
   // moves to the scalar unit, SGPR spills go from 74 to 99 and the kernel gets slower, 62.5 us against 58.7)
@@ -1234,7 +1239,7 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   if ((mode & 0xFF) != 1) return;
   const int count = (int)(mode >> 8);
   Lds l;
-  mg_carve_uses(smem, &l, a.A, a.NAmax, a.SG, DCL ? a.dc_words : 0);
+  mg_carve_uses<true>(smem, &l, a.A, a.NAmax, a.SG, DCL ? a.dc_words : 0);
   MG_STAMP(8);
   // every staging load is independent of the others: issue them together, one barrier
   {
@@ -1350,7 +1355,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
 #endif
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0, -1, a.NCmax);
+  mg_carve<true>(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, 0, DCL ? a.dc_words : 0, 0, 0, 0, -1, a.NCmax);
   if (BIG) l.grid = a.big_grid + (size_t)e * a.HW;
   MG_STAMP(8);
   if (DCL) {
@@ -1479,7 +1484,7 @@ __global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_ker
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
-  mg_carve_obs(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
+  mg_carve_obs<true>(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
                a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
     l.grid = a.big_grid + (size_t)e * a.HW;
@@ -1557,7 +1562,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;
-  mg_carve(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP,
+  mg_carve<true>(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP,
            a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
     l.grid = a.big_grid + (size_t)e * a.HW;
@@ -1965,10 +1970,10 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   // env lives in HBM, and the observation / reset kernels read the agent records in HBM too.
   const size_t LDS_MAX = 160 * 1024;
   bool big = false;
-  size_t lds = mg_carve(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, -1, NCmax);
+  size_t lds = mg_carve<false>(nullptr, nullptr, HWp, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, -1, NCmax);
   if (lds > LDS_MAX) {
     big = true;
-    lds = mg_carve(nullptr, nullptr, 0, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, 0, NCmax);
+    lds = mg_carve<false>(nullptr, nullptr, 0, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, 0, NCmax);
     if (lds > LDS_MAX)
       return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (" + std::to_string(lds) + " bytes)");
   }
@@ -2012,17 +2017,17 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   h->dc_lds = !big && k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
   int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
-  h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0, -1, NCmax);
-  h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
+  h->lds_act = mg_carve<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0, -1, NCmax);
+  h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX) {
     h->dc_lds = false;
-    h->lds_act = mg_carve(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0, -1, NCmax);
-    h->lds_obs = mg_carve_obs(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
+    h->lds_act = mg_carve<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0, -1, NCmax);
+    h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   }
   if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
                 ", obs " + std::to_string(h->lds_obs) + " bytes)");
-  h->lds_uses = mg_carve_uses(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
+  h->lds_uses = mg_carve_uses<false>(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
   {
     // the cap on dynamic LDS is a per-function setting shared by every handle of the process: raise it once
     const int cap = (int)LDS_MAX;
