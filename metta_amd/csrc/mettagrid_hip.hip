@@ -338,26 +338,34 @@ __device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lan
 
 // One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
 // MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
-template <int NR, bool HOT = false>
-__device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
-                                      const DAgent* me, int action, uint8_t* __restrict__ row,
-                                      const uint32_t (&pk)[MG_MAX_ROUNDS], int lane) {
-  const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W, P = ec.P;
-  const uint32_t rc = *(const uint32_t*)me;  // r | c << 16 (first two fields of the record)
+// Window lookups of one agent, all rounds (independent LDS reads: they overlap, and the caller issues them for both
+// agents of a pair before either row is written).  Window offsets never exceed the radius, so "inside the window and
+// the map" is just "inside the map".  meta = heap offset | token count << 16 per window cell.
+template <int NR, bool HOT>
+__device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
+                                                 const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
+                                                 uint32_t& rc) {
+  const int H = ec.H, W = ec.W, P = ec.P;
+  rc = *(const uint32_t*)me;  // r | c << 16 (first two fields of the record)
   const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
-  // window lookups of all rounds first (independent LDS reads overlap).  Window offsets never exceed the radius, so
-  // "inside the window and the map" is just "inside the map".
-  uint32_t meta[NR];
 #pragma unroll
   for (int q = 0; q < NR; q++) {
-    meta[q] = 0;
     int p = q * 64 + lane;
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
     const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && (HOT || !(a.diag & 512));
     // no branches: cells outside the map read cell 0 and are masked; empty cells read the zero entry ocnt[-1]
     const uint32_t cv = l.grid[ok ? __mul24(r, W) + c : 0];
-    meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];  // heap offset | token count << 16
+    meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];
   }
+}
+
+template <int NR, bool HOT = false>
+__device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
+                                      const DAgent* me, int action, uint8_t* __restrict__ row,
+                                      const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, const uint32_t (&meta)[NR],
+                                      const uint32_t rc) {
+  const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W;
+  const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
   // Global tokens at the centre.  The fixed ones (episode completion, last action, last reward) sit one per lane,
   // prepared once per wave (GlobalTok); goal and compass tokens depend on the agent and follow from lane 0.
   int base = gt.n;
@@ -465,6 +473,10 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   const DAgent* me0 = l.ag + wave * group;
   const uint32_t roff_step = (uint32_t)(nwaves * group) * (uint32_t)row_bytes;
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
+  {
+    uint32_t meta[group][NR], rc[group];
+#pragma unroll
+    for (int h = 0; h < group; h++) mg_window_lookup<NR, PAIRS>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
 #pragma unroll
     for (int h = 0; h < group; h++) {
       const int ai = a0 + h;
@@ -481,7 +493,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
-      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, pk, lane);
+      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, pk, lane, meta[h], rc[h]);
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {
@@ -519,6 +531,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
 }
 
 // The headline shape (window of at most 128 cells, rows of 8 mod 16 bytes in pairs: 11 x 11 window, 200 tokens) has
