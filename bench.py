@@ -14,7 +14,7 @@ collective is the RCCL all-reduce of the finished-episode summary vector every 1
 
 Prints ONE JSON line on rank 0.  `roofline`: algorithmic bytes per launch (1035 B per agent-step, SURVEY §8d:
 610 B boundary + ~425 B state) / mean kernel duration measured with HIP events on the launch stream over the timed
-steps; `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
+steps (every 8th step is bracketed: the event pair is not free); `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
 `cpu_baseline`: the reference's own compiled core (oracle/_ref, kind "reference") or the oracle port, stepped on
 the host cores over a bounded sample of the same workload, rank 0 / N=1 only.
 """
@@ -37,6 +37,7 @@ ENVS_PER_GPU = 4096
 AGENTS = 24
 ALGO_BYTES_PER_AGENT_STEP = 1035.0  # 610 B boundary + ~425 B state (arena)
 OBS_BYTES_PER_AGENT_STEP = 970.0  # the observation kernel alone, 600 B written + ~370 B read
+PROFILE_STRIDE = 8  # steps between HIP-event brackets in the timed region
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 
 
@@ -200,7 +201,8 @@ def main() -> None:
     if use_dist:
         reduce_summary()  # communicator set-up and first-use costs stay out of the timed region
     sync_all()
-    batch.set_profiling(True)
+    # HIP events around every 8th step of the timed region: an event pair per step costs ~7 % of the step it times
+    batch.set_profiling(True, stride=PROFILE_STRIDE)
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     sync_all()
@@ -265,6 +267,7 @@ def main() -> None:
                 "kernel": "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel (the three launches of one step)",
                 "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
                 "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
+                "kernel_ms_samples": int(len(kernel_ms)),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "obs_kernel": {
                     "ms_mean": float(obs_ms.mean()) if len(obs_ms) else None,

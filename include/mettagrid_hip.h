@@ -145,6 +145,9 @@ int mg_summary_buffer(mg_handle* h, double** device_ptr, int32_t* n);
  * recorded steps, writes their durations in milliseconds and restarts recording.  bench.py's roofline line.
  * mg_set_profiling(h, 2) brackets the observation kernel only (SURVEY.md §8d metric 2: obs-encode GB/s). */
 int mg_set_profiling(mg_handle* h, int enabled);
+/* Record only every `stride`-th step (default 1).  The event pair is not free: on a 90 us step it costs about 7 % of
+ * the wall clock, so a benchmark that times itself samples (bench.py: every 8th step of the timed region). */
+int mg_set_profiling_stride(mg_handle* h, int stride);
 int mg_profile_read(mg_handle* h, float* ms, int max_steps, int* n_steps);
 
 /* Diagnostic (no reference counterpart): enable / read per-environment cycle stamps u64[E][16] of the observation

@@ -175,8 +175,10 @@ class MettaGridBatch:
     def end_episode(self, env: int = -1) -> None:
         native.check(self.L.mg_end_episode(self._h, int(env), self._stream()))
 
-    def set_profiling(self, enabled) -> None:
-        """False/0 off, True/1 time whole steps, 2 time the observation kernel only (HIP events on the launch stream)."""
+    def set_profiling(self, enabled, stride: int = 1) -> None:
+        """False/0 off, True/1 time whole steps, 2 time the observation kernel only (HIP events on the launch stream).
+        `stride`: record every stride-th step only (the event pair costs about 7 % of a 90 us step)."""
+        native.check(self.L.mg_set_profiling_stride(self._h, int(stride)))
         native.check(self.L.mg_set_profiling(self._h, int(enabled)))
 
     def profile_read(self, max_steps: int = 4096) -> np.ndarray:

@@ -69,6 +69,7 @@ SYMBOLS = {
     "mg_summary_buffer": (ct.c_int, [_vp, ct.POINTER(ct.POINTER(ct.c_double)), _i32p]),
     "mg_finished_summary": (ct.c_int, [_vp, _f64p, ct.c_int, _vp]),
     "mg_set_profiling": (ct.c_int, [_vp, ct.c_int]),
+    "mg_set_profiling_stride": (ct.c_int, [_vp, ct.c_int]),
     "mg_profile_read": (ct.c_int, [_vp, _f32p, ct.c_int, ct.POINTER(ct.c_int)]),
     "mg_debug_stamps": (ct.c_int, [_vp, ct.POINTER(ct.c_uint64), ct.c_int]),
     "mg_destroy": (ct.c_int, [_vp]),
