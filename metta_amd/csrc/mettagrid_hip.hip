@@ -2043,6 +2043,9 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
                 ", obs " + std::to_string(h->lds_obs) + " bytes)");
   h->lds_uses = mg_carve_uses<false>(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
+  if (getenv("MG_VERBOSE"))
+    fprintf(stderr, "mettagrid_hip: LDS bytes per workgroup: act %zu, obs %zu, uses %zu (dc words %d, obs prefix %d, heap %d tokens, %d objects)\n",
+            h->lds_act, h->lds_obs, h->lds_uses, k.dc_words, k.dc_obs_words, HEAP, NOBJ);
   {
     // the cap on dynamic LDS is a per-function setting shared by every handle of the process: raise it once
     const int cap = (int)LDS_MAX;

@@ -164,3 +164,31 @@ def test_buffers_dtype_errors_and_dlpack():
     o = torch.from_dlpack(b.observations)  # the tensors are DLPack producers themselves
     assert o.data_ptr() == b.observations.data_ptr()
     b.close()
+
+
+@pytest.mark.gpu
+def test_profiling_stride_samples_every_nth_step():
+    """mg_set_profiling_stride: HIP-event brackets around every n-th step only (bench.py samples every 8th)."""
+    import torch
+
+    from metta_amd.batch import MettaGridBatch
+    from metta_amd.builder import make_arena
+
+    cfg = make_arena(24)
+    rng = np.random.default_rng(0)
+    maps = [cfg.game.map_builder.build(rng) for _ in range(2)]
+    b = MettaGridBatch(cfg, 8, maps, device=0, init_obs_passes=2, seeds=list(range(8)), map_ids=[e % 2 for e in range(8)])
+    acts = torch.zeros(8 * 24, dtype=torch.int32, device="cuda")
+    b.set_profiling(True, stride=4)
+    for _ in range(16):
+        b.step(acts)
+    ms = b.profile_read(4096)
+    assert len(ms) == 4 and (ms > 0).all()
+    b.set_profiling(True)
+    for _ in range(5):
+        b.step(acts)
+    assert len(b.profile_read(4096)) == 5
+    b.set_profiling(False)
+    with pytest.raises(RuntimeError, match="stride"):
+        b.set_profiling(True, stride=0)
+    b.close()
