@@ -86,3 +86,22 @@ def compute_advantage(
         values, rewards, dones, importance_sampling_ratio, advantages, gamma, gae_lambda, vtrace_rho_clip, vtrace_c_clip
     )
     return advantages
+
+
+def normalize_advantage_distributed(adv: Tensor, norm_adv: bool = True) -> Tensor:
+    """metta/rl/advantage.py:122-150: normalise advantages over ALL ranks' elements with one all-reduce of
+    [sum, sum of squares, count] (RCCL on ROCm, `backend="nccl"`); single process: `(adv - mean) / (std + 1e-8)`
+    with torch's unbiased std, as the reference does.  Shape is preserved."""
+    if not norm_adv:
+        return adv
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        flat = adv.reshape(-1)
+        stats = torch.stack(
+            [flat.sum(), (flat * flat).sum(), torch.tensor(float(flat.numel()), dtype=adv.dtype, device=adv.device)]
+        )
+        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
+        mean = stats[0] / stats[2]
+        var = stats[1] / stats[2] - mean * mean
+        std = torch.sqrt(var.clamp(min=1e-8))
+        return (adv - mean) / (std + 1e-8)
+    return (adv - adv.mean()) / (adv.std() + 1e-8)
