@@ -118,8 +118,9 @@ def cpu_baseline(budget_s: float = 10.0) -> dict:
         "unit": "agent-steps/s",
         "cores": cores,
         "kind": kind,
-        "sample": f"{cores} processes x {n_envs} arena-24 envs stepped serially for ~{budget_s:.0f} s each "
-        f"(same config/maps/action distribution; {'reference C++ core compiled from /root/reference' if kind == 'reference' else 'oracle port'})",
+        "sample": f"{cores} independent processes x {n_envs} arena-24 envs stepped serially for ~{budget_s:.0f} s each, "
+        "no vecenv IPC (no shared-memory buffers, no semaphores: an upper bound for the reference's multiprocess CPU vecenv); "
+        f"same config/maps/action distribution; {'reference C++ core compiled from /root/reference' if kind == 'reference' else 'oracle port'}",
     }
 
 

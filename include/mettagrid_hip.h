@@ -118,6 +118,17 @@ int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream);
 int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, uint32_t* seed, uint32_t* episodes,
                 void* stream);
 
+/* Error surfacing.  An environment that leaves reference parity (RNG window overflow, a frozen agent on the
+ * attack-free fast path, a chest work list overflow) sets bits in its `error` word (mg_env_table column 7); the step
+ * kernels OR them into one sticky device word that a caller can read without touching every environment:
+ * mg_status_buffer returns u32[4] in HBM = {OR of error bits, finished episodes (count), 0, 0};
+ * mg_check_errors synchronises, and fails with a decoded message naming the first offending environment.
+ * (Reference: the C++ core throws std::runtime_error out of step(); there is no silent corruption mode.) */
+int mg_status_buffer(mg_handle* h, uint32_t** device_ptr, int32_t* n);
+int mg_check_errors(mg_handle* h, void* stream);
+/* Diagnostic (tests): set the error word of one environment; the next step publishes it like a real fault. */
+int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits);
+
 /* All environments' bookkeeping words in one copy: u32 out[E][8] = {current_step, rng index, seed, map_id,
  * episodes finished, pending early-reset step, done flag, error flag}.  (Reference: `current_step`, `_seed`; the
  * episode counter lets a host poll for finished episodes every k steps instead of every step.) */

@@ -21,6 +21,26 @@ from metta_amd.stats_decode import decode_episode_stats
 from metta_amd.umap import order_from_pydict
 
 
+class _HandleOwner:
+    """Owns the native handle.  Tensors aliasing the library's HBM hold a reference to this object -- not to the
+    `MettaGridBatch` -- so there is no reference cycle through torch's storage deleter, and the handle is destroyed
+    when the batch AND every tensor it handed out are gone (or at once by `MettaGridBatch.close()`)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def destroy(self) -> None:
+        if self.h is not None and self.h:
+            self.lib.mg_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class _DevArray:
     """Minimal `__cuda_array_interface__` carrier so torch can alias a raw device pointer."""
 
@@ -32,7 +52,10 @@ class _DevArray:
             "version": 3,
             "strides": None,
         }
-        self._owner = owner  # keeps the handle alive while tensors exist
+        self._owner = owner  # the _HandleOwner: keeps the HBM alive while tensors exist
+
+
+_ALIASED = ("observations", "rewards", "terminals", "truncations", "actions", "masks", "episode_rewards", "action_success")
 
 
 def _p(a: np.ndarray, t):
@@ -65,6 +88,7 @@ class MettaGridBatch:
         blob = np.ascontiguousarray(self.compiled.blob, dtype=np.int32)
         self._h = ct.c_void_p()
         native.check(self.L.mg_create(_p(blob, ct.c_int32), blob.size, self.num_envs, self.device_index, ct.byref(self._h)))
+        self._owner = _HandleOwner(self.L, self._h)
         self.set_maps(maps)
         b = native.MgBuffers()
         native.check(self.L.mg_get_buffers(self._h, ct.byref(b)))
@@ -72,7 +96,7 @@ class MettaGridBatch:
         self.num_actions = int(b.num_actions)
 
         def alias(ptr, shape, typestr, dtype):
-            t = torch.as_tensor(_DevArray(ptr, shape, typestr, self), device=self.device)
+            t = torch.as_tensor(_DevArray(ptr, shape, typestr, self._owner), device=self.device)
             assert t.dtype == dtype and t.data_ptr() == ptr
             return t
 
@@ -369,15 +393,29 @@ class MettaGridBatch:
         ptr, n = ct.POINTER(ct.c_double)(), ct.c_int32()
         native.check(self.L.mg_summary_buffer(self._h, ct.byref(ptr), ct.byref(n)))
         addr = ct.cast(ptr, ct.c_void_p).value
-        return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<f8", self), device=self.device)
+        return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<f8", self._owner), device=self.device)
+
+    def status_tensor(self):
+        """u32[4] in HBM as a torch int32 tensor: [0] OR of every environment's error bits (sticky), [1] episodes
+        finished since creation.  Reading it needs no per-environment copy; `check_errors` is the raising form."""
+        ptr, n = ct.POINTER(ct.c_uint32)(), ct.c_int32()
+        native.check(self.L.mg_status_buffer(self._h, ct.byref(ptr), ct.byref(n)))
+        addr = ct.cast(ptr, ct.c_void_p).value
+        return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<i4", self._owner), device=self.device)
+
+    def check_errors(self) -> None:
+        """Raise RuntimeError if any environment flagged an internal error (the reference's core throws out of
+        `step()`; here the flag is raised on the device and surfaces at the caller's next synchronisation point)."""
+        native.check(self.L.mg_check_errors(self._h, self._stream()))
 
     def close(self) -> None:
-        if getattr(self, "_h", None) is not None and self._h:
-            self.L.mg_destroy(self._h)
-            self._h = ct.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """Free the handle's HBM now.  Every tensor this object handed out (`observations`, `rewards`, ...,
+        `summary_tensor()`, DLPack capsules, whatever `recv()` returned) aliases that memory and is INVALID afterwards
+        -- clone what must outlive the environment before closing.  The object's own aliases are dropped here.
+        Without `close()` the memory is released when the batch and all of those tensors have been collected."""
+        owner = getattr(self, "_owner", None)
+        if owner is not None and owner.h is not None:
+            for name in _ALIASED:
+                setattr(self, name, None)
+            owner.destroy()
+        self._h = ct.c_void_p()

@@ -25,7 +25,7 @@
 #define ADV_TT 64
 #define ADV_LD (ADV_TT + 1)
 
-extern int mg_fail_msg(const std::string& m);  // mettagrid_hip.hip: sets mg_last_error(), returns -1
+extern int mg_fail_msg(const std::string& m);  // mettagrid_hip.hip: sets mg_last_error(), returns 1
 
 // Staging registers of one tile: 4 inputs x ADV_ROWS x ADV_TT floats over 64 lanes.
 template <bool VEC4>

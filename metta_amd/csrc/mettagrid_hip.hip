@@ -71,6 +71,7 @@ struct KArgs {
   float* fin_ep_rewards;  // [E][A]
   uint32_t* fin_steps;    // [E]
   double* summary;        // [3 + SG]
+  uint32_t* status;       // [4]: OR of every env's error bits | finished episodes (count) | 2 spare words
   uint8_t* obs;
   float* rewards;
   uint8_t* term;
@@ -858,6 +859,7 @@ __device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t step
   }
   if (tid == 0) {
     a.fin_steps[e] = steps;
+    atomicAdd(&a.status[1], 1u);
     atomicAdd(&a.summary[0], 1.0);
     atomicAdd(&a.summary[1], (double)steps);
   }
@@ -1228,6 +1230,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
     env.mt_idx = new_idx;
     a.env[e] = env;
     a.mode[e] = n_pending > 0 ? (1u | ((uint32_t)n_pending << 8)) : 0u;
+    if (env.error) atomicOr(&a.status[0], env.error);  // sticky: the host reads one word for all environments
   }
 }
 
@@ -1483,6 +1486,7 @@ __global__ __launch_bounds__(MG_ACT_THREADS) void mg_act_kernel(KArgs a) {
       if (l.flags[1] & 1) env.error |= 1u;
       if (l.flags[1] & 8) env.error |= 8u;
       a.env[e] = env;
+      if (env.error) atomicOr(&a.status[0], env.error);
     }
   }
 }
@@ -1706,6 +1710,17 @@ int mg_fail_msg(const std::string& m) { return fail(m); }  // for the library's 
     if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e));                 \
   } while (0)
 
+// env.error / status[0] bits (kernels: mg_act_fast_kernel, mg_act_kernel)
+static std::string mg_error_text(uint32_t bits) {
+  std::string t;
+  if (bits & 1u) t += "RNG window overflow (more MT19937 outputs needed in one step than staged); ";
+  if (bits & 4u) t += "frozen agent on the wave-parallel act path (configuration misclassified as attack-free); ";
+  if (bits & 8u) t += "more than 24 chests within an assembler's search distance (work list overflow); ";
+  if (bits & ~13u) t += "unknown error bits " + std::to_string(bits & ~13u) + "; ";
+  if (!t.empty()) t.resize(t.size() - 2);
+  return t;
+}
+
 struct mg_handle {
   MgConfig cfg;
   int device = 0;
@@ -1720,6 +1735,7 @@ struct mg_handle {
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool maps_set = false;
+  bool needs_reset = true;     // a new map pool invalidates every environment's map id: mg_reset(all) comes first
   int profiling = 0;  // 0 off, 1 whole step, 2 observation kernel only
   int prof_stride = 1;         // record every prof_stride-th step (the event pair itself costs ~7 % of a 90 us step)
   unsigned long long prof_tick = 0;
@@ -1756,7 +1772,11 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail("mg_create: no HIP device available (this library has no CPU fallback)");
-  auto h = std::make_unique<mg_handle>();
+  // every early `return` below releases what was created so far (device buffers, streams, events)
+  struct Destroy {
+    void operator()(mg_handle* p) const { (void)mg_destroy(p); }
+  };
+  std::unique_ptr<mg_handle, Destroy> h(new mg_handle());
   try {
     h->cfg = MgConfig::parse(cfg_blob, cfg_words);
   } catch (const std::exception& ex) {
@@ -1825,6 +1845,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &k.fin_ep_rewards, N)) return 1;
   if (dalloc(h.get(), &k.fin_steps, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.summary, (size_t)(3 + k.SG))) return 1;
+  if (dalloc(h.get(), &k.status, 4)) return 1;
   if (dalloc(h.get(), &k.obs, N * c.T * 3)) return 1;
   if (dalloc(h.get(), &k.rewards, N)) return 1;
   if (dalloc(h.get(), &k.term, N)) return 1;
@@ -1877,6 +1898,10 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     }
   }
   HIPCHK(hipSetDevice(h->device));
+  // A second call on a live handle replaces the pool: every environment keeps a stale map id until mg_reset, so the
+  // handle refuses to step in between (and stays unusable if this call fails half way).
+  HIPCHK(hipDeviceSynchronize());
+  h->maps_set = false;
   const MgConfig& c = h->cfg;
   KArgs& k = h->k;
   // (the assembler / chest slot counts are known only after the scan: codes are patched below)
@@ -2121,6 +2146,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
   h->maps_set = true;
+  h->needs_reset = true;
+  if (k.map_stride >= num_maps) k.map_stride %= num_maps;
   return 0;
 }
 
@@ -2146,6 +2173,7 @@ int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds,
   if (!h) return fail("mg_reset: NULL handle");
   if (!h->maps_set) return fail("mg_reset: call mg_set_maps first");
   if (!seeds || !map_ids) return fail("mg_reset: seeds and map_ids are required");
+  if (h->needs_reset && env_ids) return fail("mg_reset: the first reset after mg_set_maps must cover every environment (env_ids = NULL)");
   HIPCHK(hipSetDevice(h->device));
   if (!env_ids) n = h->E;
   if (n < 1 || n > h->E) return fail("mg_reset: bad environment count");
@@ -2167,13 +2195,24 @@ int mg_reset(mg_handle* h, const int32_t* env_ids, int n, const uint32_t* seeds,
   else hipLaunchKernelGGL(mg_reset_kernel<false>, dim3((unsigned)n), dim3(MG_THREADS), h->lds_bytes, s, k);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(s));  // the scratch lists are reused by the next call
+  if (!env_ids) h->needs_reset = false;
+  return 0;
+}
+
+// The hot entry points launch on the handle's device whatever the caller's current device is; the switch is only
+// made when it differs (hipGetDevice is a thread-local read).
+static int mg_use_device(mg_handle* h) {
+  int cur = -1;
+  HIPCHK(hipGetDevice(&cur));
+  if (cur != h->device) HIPCHK(hipSetDevice(h->device));
   return 0;
 }
 
 #define MG_PROFILE_RING 4096
 static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
   if (!h) return fail("mg_step: NULL handle");
-  if (!h->maps_set) return fail("mg_step: call mg_set_maps and mg_reset first");
+  if (!h->maps_set || h->needs_reset) return fail("mg_step: call mg_set_maps and mg_reset first");
+  if (int rc = mg_use_device(h)) return rc;
   hipStream_t s = (hipStream_t)stream;
   KArgs k = h->k;
   if (actions) k.actions = actions;
@@ -2227,8 +2266,9 @@ int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream) {
 
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride) {
   if (!h) return fail("mg_set_auto_reset: NULL handle");
+  if (map_stride < 0) return fail("mg_set_auto_reset: map_stride must be >= 0");
   h->k.auto_reset = enabled ? 1 : 0;
-  h->k.map_stride = map_stride;
+  h->k.map_stride = h->maps_set && h->k.P > 0 ? map_stride % h->k.P : map_stride;
   return 0;
 }
 
@@ -2264,6 +2304,7 @@ int mg_get_buffers(mg_handle* h, mg_buffers* out) {
 int mg_end_episode(mg_handle* h, int env, void* stream) {
   if (!h) return fail("mg_end_episode: NULL handle");
   if (env >= h->E) return fail("mg_end_episode: environment id out of range");
+  if (int rc = mg_use_device(h)) return rc;
   int N = h->E * h->cfg.A;
   hipLaunchKernelGGL(mg_end_episode_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->k, env);
   HIPCHK(hipGetLastError());
@@ -2324,12 +2365,48 @@ int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, 
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   DEnv d;
   HIPCHK(hipMemcpy(&d, h->k.env + env, sizeof(d), hipMemcpyDeviceToHost));
-  if (d.error) return fail("environment " + std::to_string(env) + " flagged an internal error (RNG window overflow)");
+  if (d.error) return fail("environment " + std::to_string(env) + " flagged an internal error: " + mg_error_text(d.error));
   if (current_step) *current_step = d.step;
   if (map_id) *map_id = (int32_t)d.map_id;
   if (seed) *seed = d.seed;
   if (episodes) *episodes = d.episodes;
   return 0;
+}
+
+int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
+  if (!h) return fail("mg_debug_inject_error: NULL handle");
+  if (env < 0 || env >= h->E) return fail("mg_debug_inject_error: environment id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&h->k.env[env].error, &bits, 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int mg_status_buffer(mg_handle* h, uint32_t** device_ptr, int32_t* n) {
+  if (!h || !device_ptr || !n) return fail("mg_status_buffer: NULL argument");
+  *device_ptr = h->k.status;
+  *n = 4;
+  return 0;
+}
+
+int mg_check_errors(mg_handle* h, void* stream) {
+  if (!h) return fail("mg_check_errors: NULL handle");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  uint32_t st[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpy(st, h->k.status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[0] == 0) return 0;
+  // name the first offending environment
+  std::vector<DEnv> envs((size_t)h->E);
+  HIPCHK(hipMemcpy(envs.data(), h->k.env, envs.size() * sizeof(DEnv), hipMemcpyDeviceToHost));
+  int first = -1, count = 0;
+  for (int e = 0; e < h->E; e++)
+    if (envs[(size_t)e].error) {
+      if (first < 0) first = e;
+      count++;
+    }
+  return fail("mg_check_errors: " + std::to_string(count) + " environment(s) left reference parity (first: env " +
+              std::to_string(first) + "): " + mg_error_text(st[0]));
 }
 
 int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream) {

@@ -119,8 +119,21 @@ class MettaGridDeviceVecEnv:
         self._episodes_seen = np.zeros(self.num_environments, dtype=np.int64)
         self._per_label_rewards: dict[str, float] = {}
         self._done_prev = None
-        self.stats_every = 1  # poll finished episodes every k steps (1 = like the reference; larger = fewer syncs)
+        # How finished episodes reach `infos`:
+        #   0 (default)  no host synchronisation in send(): after each step the 16-byte device status word (error bits,
+        #                finished-episode counter) is copied asynchronously into pinned memory; a later send() that finds
+        #                the copy complete and the counter advanced collects the snapshots the step kernel took when it
+        #                restarted those environments.  infos arrive one or more steps late, never block the stream.
+        #   1            like the reference: episodes that ended on a step are reported by the very next recv()
+        #                (one host sync per step).
+        #   k > 1        poll the per-env episode counters every k steps (one sync per k steps).
+        self.stats_every = 0
         self._steps = 0
+        self._status_dev = self.batch.status_tensor()
+        self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._status_event = None
+        self._finished_seen = 0
+        self.host_syncs = 0  # blocking device->host reads issued by send() (tests assert on it)
 
     # ---- buffers (pufferlib.set_buffers names, PUF/pufferlib.py:18-45) ------------------------------------
     @property
@@ -166,6 +179,8 @@ class MettaGridDeviceVecEnv:
         self._episodes_seen[:] = 0
         self.infos = []
         self._done_prev = None
+        self._status_event = None
+        self._finished_seen = int(self._status_dev[1].item()) & 0xFFFFFFFF
         self.flag = RECV
 
     def recv(self):
@@ -191,10 +206,41 @@ class MettaGridDeviceVecEnv:
             actions = actions.to(torch.int32)  # the vecenv casts like pufferlib's send (vector.py), the env itself is strict
         b.step(actions.reshape(-1))
         self._steps += 1
-        if self.stats_every == 1:
+        if self.stats_every == 0:
+            self._poll_status()
+        elif self.stats_every == 1:
+            self.host_syncs += 1
             self._collect_infos()  # episodes that ended on this step: same recv() as the reference delivers them
+            b.check_errors()
         elif self._steps % self.stats_every == 0:
+            self.host_syncs += 1
             self._collect_finished()  # poll the episode counters; infos arrive up to stats_every steps late
+
+    def _poll_status(self) -> None:
+        """Non-blocking: look at the last completed copy of the status word, then queue the next copy."""
+        torch = self.batch._torch
+        ev = self._status_event
+        if ev is not None and ev.query():
+            err, finished = int(self._status_host[0]) & 0xFFFFFFFF, int(self._status_host[1]) & 0xFFFFFFFF
+            self._status_event = None
+            if err:
+                self.batch.check_errors()  # synchronises and raises with the decoded message
+            if finished != self._finished_seen:
+                self._finished_seen = finished
+                self.host_syncs += 1
+                self._collect_finished()
+        if self._status_event is None:
+            self._status_host.copy_(self._status_dev, non_blocking=True)
+            self._status_event = torch.cuda.Event()
+            self._status_event.record(torch.cuda.current_stream(self.batch.device))
+
+    def flush_infos(self) -> list:
+        """Synchronise and collect every finished episode not yet reported (end of a rollout / before closing)."""
+        self.host_syncs += 1
+        self._collect_finished()
+        self.batch.check_errors()
+        infos, self.infos = self.infos, []
+        return infos
 
     def reset(self, seed: int = 42):
         self.async_reset(seed)
@@ -210,6 +256,8 @@ class MettaGridDeviceVecEnv:
         pass
 
     def close(self) -> None:
+        """Frees the HBM: tensors returned by recv() / reset() / step() alias it and are invalid afterwards."""
+        self._status_dev = None
         self.batch.close()
 
     # ---- StatsTracker.on_episode_end (PY/envs/stats_tracker.py:26-107) ---------------------------------------
@@ -250,6 +298,8 @@ class MettaGridDeviceVecEnv:
         takes when it restarts an environment (only the latest finished episode of an env is kept)."""
         b = self.batch
         table = b.env_table()
+        if table[:, 7].any():
+            b.check_errors()  # raises, naming the first environment and the decoded bits
         A = self.agents_per_env
         for e in np.nonzero(table[:, 4] > self._episodes_seen)[0].tolist():
             self._episodes_seen[e] = int(table[e, 4])

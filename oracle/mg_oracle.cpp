@@ -18,7 +18,7 @@
 // paired-draw Fisher-Yates with the Lemire bounded sampler, std::discrete_distribution, and
 // unordered_map<uint8_t,...> iteration order (for inventories).
 //
-// Pinning: tests/test_oracle_vs_reference.py compares it, step by step and bit for bit, with the reference's own
+// Pinning: tests/test_oracle_golden.py (test_oracle_vs_reference_core_fuzz) compares it, step by step and bit for bit, with the reference's own
 // compiled core (oracle/_ref, built by oracle/Makefile from /root/reference) and tests/golden/* holds vectors
 // emitted by that reference.
 #include <algorithm>
