@@ -77,6 +77,16 @@ int mg_step(mg_handle* h, void* stream);
  * `MettaGridPufferEnv.step` (mettagrid_puffer_env.py:166-169). */
 int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream);
 
+/* Allocation-free step.  No counterpart in the reference: it is for callers that cannot allocate -- code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results as mg_step /
+ * mg_step_actions (`device_actions` NULL = the handle's own action buffer), but the per-step hand-over buffers
+ * between the action and the observation kernels (executed action per agent, per-env mode word, pending assembler
+ * uses) live in a file-scope device array of the library instead of the handle's own buffers; the call itself
+ * performs no hipMalloc / hipFree / allocating library routine.  Limits: num_envs * num_agents <= 131072 and
+ * num_envs <= 16384, else an error.  All handles on one GPU share that GPU's array: calls that overlap in time on
+ * one GPU (different streams / threads) race; calls on one stream, or serialised by the caller, do not. */
+int mg_step_noalloc(mg_handle* h, const int32_t* device_actions, void* stream);
+
 /* Auto-reset policy used by mg_step: enabled (0/1) and how the next map is chosen: map_id += map_stride (mod P). */
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride);
 

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1749,6 +1750,34 @@ struct mg_handle {
   uint8_t* masks = nullptr;    // all ones (reference: mettagrid_c.cpp:983-995)
 };
 
+// ---- static scratch of the allocation-free step (mg_step_noalloc) ---------------------------------------------
+// The hand-over buffers between the action kernel(s) and the observation kernel of one step -- executed action per
+// agent, per-env mode word, pending assembler uses -- as one file-scope device array instead of the handle's
+// hipMalloc'ed ones.  Every GPU the library runs on holds its own copy until the process ends; the array's name is
+// only a host-side stand-in, the device address is looked up once per device (mg_scratch_init) and kept.
+#define MG_NOALLOC_MAX_AGENTS 131072  /* E * A */
+#define MG_NOALLOC_MAX_ENVS 16384
+#define MG_SCRATCH_PEND_BYTES ((size_t)MG_NOALLOC_MAX_AGENTS * 32)
+#define MG_SCRATCH_EXEC_BYTES ((size_t)MG_NOALLOC_MAX_AGENTS * 4)
+#define MG_SCRATCH_MODE_BYTES ((size_t)MG_NOALLOC_MAX_ENVS * 4)
+#define MG_SCRATCH_BYTES (MG_SCRATCH_PEND_BYTES + MG_SCRATCH_EXEC_BYTES + MG_SCRATCH_MODE_BYTES)  /* 4.56 MiB */
+static __device__ __align__(256) unsigned char mg_scratch[MG_SCRATCH_BYTES];
+#define MG_MAX_DEVICES 64
+static unsigned char* g_scratch_ptr[MG_MAX_DEVICES];  // per device: address of that GPU's copy of mg_scratch
+static std::mutex g_scratch_mu;
+
+// Once per device, with that device current (called by mg_create).
+static int mg_scratch_init(int device) {
+  if (device < 0 || device >= MG_MAX_DEVICES) return fail("mg_create: device id out of range");
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[device]) return 0;
+  void* p = nullptr;
+  HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(mg_scratch)));
+  if (!p) return fail("mg_create: hipGetSymbolAddress(mg_scratch) returned NULL");
+  g_scratch_ptr[device] = (unsigned char*)p;
+  return 0;
+}
+
 template <class T>
 static int dalloc(mg_handle* h, T** p, size_t n, bool map_alloc = false) {
   void* q = nullptr;
@@ -1798,6 +1827,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   } else {
     HIPCHK(hipGetDevice(&h->device));
   }
+  if (mg_scratch_init(h->device)) return 1;
   h->E = num_envs;
   KArgs& k = h->k;
   memset(&k, 0, sizeof(k));
@@ -2209,13 +2239,26 @@ static int mg_use_device(mg_handle* h) {
 }
 
 #define MG_PROFILE_RING 4096
-static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream) {
+static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool static_scratch = false) {
   if (!h) return fail("mg_step: NULL handle");
   if (!h->maps_set || h->needs_reset) return fail("mg_step: call mg_set_maps and mg_reset first");
   if (int rc = mg_use_device(h)) return rc;
   hipStream_t s = (hipStream_t)stream;
   KArgs k = h->k;
   if (actions) k.actions = actions;
+  if (static_scratch) {
+    // same kernels, the hand-over buffers in this GPU's static array (the pointer kept by mg_scratch_init, never
+    // the array's name).  Every word the kernels read there is written earlier in the same step: nothing to clear.
+    if ((size_t)h->E * (size_t)h->cfg.A > MG_NOALLOC_MAX_AGENTS || h->E > MG_NOALLOC_MAX_ENVS)
+      return fail("mg_step_noalloc: at most " + std::to_string(MG_NOALLOC_MAX_AGENTS) + " agents (envs x agents) and " +
+                  std::to_string(MG_NOALLOC_MAX_ENVS) + " environments per handle; this handle has " +
+                  std::to_string((size_t)h->E * (size_t)h->cfg.A) + " agents in " + std::to_string(h->E) + " environments");
+    unsigned char* sp = g_scratch_ptr[h->device];
+    if (!sp) return fail("mg_step_noalloc: static scratch of this device was not initialised");
+    k.pend = sp;
+    k.exec = (int*)(sp + MG_SCRATCH_PEND_BYTES);
+    k.mode = (uint32_t*)(sp + MG_SCRATCH_PEND_BYTES + MG_SCRATCH_EXEC_BYTES);
+  }
   size_t slot = 0;
   bool prof = h->profiling && h->ev_count < MG_PROFILE_RING && (h->prof_tick++ % (unsigned)h->prof_stride) == 0;
   const bool obs_only = prof && h->profiling == 2 && h->n_split <= 1;
@@ -2262,6 +2305,10 @@ int mg_step(mg_handle* h, void* stream) { return mg_step_impl(h, nullptr, stream
 int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream) {
   if (!device_actions) return fail("mg_step_actions: NULL action buffer");
   return mg_step_impl(h, device_actions, stream);
+}
+
+int mg_step_noalloc(mg_handle* h, const int32_t* device_actions, void* stream) {
+  return mg_step_impl(h, device_actions, stream, true);  // NULL actions = the handle's own action buffer
 }
 
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride) {
