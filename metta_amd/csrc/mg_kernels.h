@@ -1,0 +1,921 @@
+// mg_kernels.h -- shared device code of the step kernels (arguments, LDS layout, encoder, restart, statistics) and the
+// host-side launchers of each kernel translation unit.  The kernels are split over several .hip files so that they
+// compile in parallel (make -j) and a change to one kernel rebuilds one file.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "mg_device_cfg.h"
+#include "mg_sim.h"
+
+#define MG_THREADS 256
+#ifndef MG_OBS_WAVES
+#define MG_OBS_WAVES 8
+#endif
+#define MG_WIN_MARGIN 32
+#define MG_STAMP(slot)                                                     \
+  do {                                                                    \
+    if (a.dbg && threadIdx.x == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + (slot)] = clock64(); \
+  } while (0)
+#define MG_DC_LDS_MAX_WORDS 6144  // 24 KiB
+
+struct KArgs {
+  const int* dc;
+  int dc_obs_words;  // prefix of the stream the observation kernel stages
+  int dc_words;  // size of the device config stream; staged in LDS when it fits (MG_DC_LDS_MAX_WORDS)
+  const uint16_t* map_cells;  // [P][HW]
+  const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
+  const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
+  const int* map_nasm;        // [P]
+  const int4* map_chest;      // [P][NCmax] (r, c, cfg, obj_id)
+  const int* map_nchest;      // [P]
+  DAgent* chests;             // [E][NCmax] chest records (inventory holders, same layout as agents)
+  const DAgent* t_chests;     // [P][NCmax] episode-start templates
+  int NCmax, TSC;             // chest slots per map; token-list stride of a chest
+  const float* map_objcount;  // [P][n_cells]
+  uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
+  const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
+  int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
+  int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
+  int CB;                  // bits needed for the largest per-object token count
+  int TSW, TSA, TSS, HEAP; // token-list strides of walls / agents / assemblers; heap size in tokens
+  DEnv* env;
+  uint32_t* mt;  // [E][624]
+  DAgent* agents;
+  DAsm* asms;
+  float* astats;       // [E][A][SA]
+  uint32_t* atouched;  // [E][A][TW]
+  float* gstats;       // [E][SG]
+  uint32_t* gtouched;  // [E][GW]
+  float* fin_astats;
+  uint32_t* fin_atouched;
+  float* fin_gstats;
+  uint32_t* fin_gtouched;
+  float* fin_ep_rewards;  // [E][A]
+  uint32_t* fin_steps;    // [E]
+  double* summary;        // [3 + SG]
+  uint32_t* status;       // [4]: OR of every env's error bits | finished episodes (count) | 2 spare words
+  uint8_t* obs;
+  float* rewards;
+  uint8_t* term;
+  uint8_t* trunc;
+  const int* actions;
+  float* ep_rewards;
+  uint8_t* success;
+  int* exec;  // [E][A] executed action of this step (last_action token)
+  uint32_t* mode;  // [E] fast path hand-off: 0 = step done, 1 | n << 8 = n pending assembler uses, 2 = general path
+  uint8_t* pend;   // [E][A][32] pending assembler uses (fast path -> general kernel)
+  int fast;        // fast (wave-parallel) act kernel in use
+  // Episode-start templates, one per map (built once by mg_set_maps with the reset kernel): restarting an
+  // environment inside a step is a handful of coalesced copies.
+  const DAgent* t_agents;     // [P][A]
+  const DAsm* t_asms;         // [P][NAmax]
+  const float* t_astats;      // [P][A][SA]
+  const uint32_t* t_atouched; // [P][A][TW]
+  const float* t_gstats;      // [P][SG]
+  const uint32_t* t_gtouched; // [P][GW]
+  uint32_t* mt_init;          // [E][624] std::mt19937(seed) state of each env's seed
+  int env_base;               // first environment of this launch (a step may be split over concurrent streams)
+  int diag;                   // diagnostic ablation bits (MG_DIAG env var): 1 = no obs stores, 8 = serial shuffle redraw, 16 / 32 / 64 = skip encode / token lists / rewards in the obs kernel
+  unsigned long long* dbg;    // optional [E][16] cycle stamps (diagnostic builds of the phases; null = off)
+  int E, A, T, SA, SG, R, NG, TW, GW, NWIN, ROWB;
+  int auto_reset, map_stride;
+  const int* reset_envs;  // reset kernel only
+  const uint32_t* reset_seeds;
+  const int* reset_maps;
+};
+
+struct Lds {
+  int* dc;
+  int* tmp;  // [8][96] scratch ints: one slot per concurrently acting lane
+  uint16_t* grid;
+  DAgent* ag;
+  DAgent* ch;       // chest records (directly after the agent records)
+  int* gsetv;       // [16] pending chest.<r>.amount values; gsetm[0] = which
+  uint32_t* gsetm;
+  DAsm* as;
+  int* gd;
+  uint32_t* dirty_amt;
+  uint32_t* dirty_misc;
+  uint16_t* order;
+  int* exec;
+  int* tok_att;
+  uint32_t* win;
+  uint32_t* mtnext;
+  float* tokacc;  // [3] tokens_written / dropped / free_space accumulators
+  int* flags;     // [4]
+  uint8_t* rows;
+  uint32_t* ocnt;   // [-1 .. NOBJ) per object this step: heap offset | token count << 16; ocnt[-1] = 0 (the empty cell)
+  uint16_t* heap;   // token lists (feature | value << 8): [NW][TSW] walls, [A][TSA] agents, [NA][TSS] assemblers
+  int4* ainfo;      // [NA] static assembler info of the map (r, c, cfg, object id)
+  uint32_t* pat;    // [P] (dr+8) | (dc+8) << 8 | location byte << 16
+};
+
+__host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Maps of one pool may differ in size (navigation suite): the kernel's copy of the arguments takes the dimensions of
+// the map its environment plays.
+__device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
+  const int2 d = a.map_dims[map_id];
+  a.H = d.x;
+  a.W = d.y;
+}
+
+// FILL = false: sizes only (host).  A compile-time switch rather than `if (l)`: a null test on the kernel's Lds
+// object can survive to the back end and then keeps the whole struct in scratch memory (every LDS access turns flat).
+template <bool FILL>
+__host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, int A, int NA, int SA, int SG, int NWIN,
+                                           int ROWB, int nwaves, int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1,
+                                           int NC = 0) {
+  if (a_rec < 0) a_rec = A;  // agent records staged in LDS (0: the kernel works on the records in HBM)
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4);
+  size_t tmpo = take(8 * 96 * 4);
+  if (FILL) {
+    l->dc = (int*)(base + dco);
+    l->tmp = (int*)(base + tmpo);
+  }
+  size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t gsv = take(16 * 4 + 16);
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
+  size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
+  size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
+  size_t oc = take(nwaves ? (size_t)(NOBJ + 1) * 4 : 0), hp = take(nwaves ? (size_t)HEAP * 2 : 0), pt = take(nwaves ? (size_t)NP * 4 : 0);
+  size_t ai = take(nwaves ? (size_t)(NA > 0 ? NA : 1) * 16 : 0);
+  if (FILL) {
+    l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ainfo = (int4*)(base + ai);
+    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
+    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64);
+    l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
+    l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
+    l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
+    l->flags = (int*)(base + fl); l->rows = (uint8_t*)(base + rows);
+  }
+  return o;
+}
+
+// LDS of the observation kernel: grid, agent/assembler records, per-wave row buffers.
+template <bool FILL>
+__host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int HW, int A, int NA, int ROWB, int nwaves,
+                                               int dcw, int NOBJ, int HEAP, int NP, int a_rec = -1, int NC = 0) {
+  if (a_rec < 0) a_rec = A;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4);
+  if (FILL) l->dc = (int*)(base + dco);
+  size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
+  size_t oc = take((size_t)(NOBJ + 1) * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
+  // the static assembler info is only read while the token lists are built, the row buffers only afterwards
+  size_t ai = rows;
+  if ((size_t)(NA > 0 ? NA : 1) * 16 > (size_t)ROWB * nwaves) ai = take((size_t)(NA > 0 ? NA : 1) * 16);
+  if (FILL) {
+    l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
+    l->ainfo = (int4*)(base + ai);
+    l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
+    l->ch = l->ag + a_rec;
+    l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
+    l->rows = (uint8_t*)(base + rows);
+  }
+  return o;
+}
+
+// LDS of the assembler-use kernel (fast mode): config stream, records, stat deltas, the hand-over records.
+template <bool FILL>
+__host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int A, int NA, int SG, int dcw) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4), tmpo = take(8 * 96 * 4);
+  size_t ag = take((size_t)A * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A * 2);
+  size_t fl = take(16), rows = take((size_t)A * 32), ai = take((size_t)(NA > 0 ? NA : 1) * 16);
+  if (FILL) {
+    l->ainfo = (int4*)(base + ai);
+    l->dc = (int*)(base + dco); l->tmp = (int*)(base + tmpo);
+    l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as); l->gd = (int*)(base + gd);
+    l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm); l->order = (uint16_t*)(base + ord);
+    l->flags = (int*)(base + fl); l->rows = (uint8_t*)(base + rows);
+    l->grid = nullptr;
+  }
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cooperative pieces (all threads of the workgroup)
+// ------------------------------------------------------------------------------------------------------------
+__device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, int tid, int nt) {
+  const uint16_t* src = a.map_cells + (size_t)map_id * a.HW;
+  int n2 = a.HW >> 1;
+  const uint32_t* s32 = (const uint32_t*)src;  // HW*2 bytes per map; maps start 4-byte aligned (HW even or padded)
+  uint32_t* d32 = (uint32_t*)l.grid;
+  if ((a.HW & 1) == 0) {
+    for (int i = tid; i < n2; i += nt) d32[i] = s32[i];
+  } else {
+    for (int i = tid; i < a.HW; i += nt) l.grid[i] = src[i];
+  }
+}
+
+__device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
+  const CellCodec cc{a.NW, a.A, a.NAmax};
+  for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = cc.agent(i);
+}
+
+__device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
+  return obj < a.NW ? obj * a.TSW
+                    : (obj < a.NW + a.A
+                           ? a.NW * a.TSW + (obj - a.NW) * a.TSA
+                           : (obj < a.NW + a.A + a.NAmax
+                                  ? a.NW * a.TSW + a.A * a.TSA + (obj - a.NW - a.A) * a.TSS
+                                  : a.NW * a.TSW + a.A * a.TSA + a.NAmax * a.TSS + (obj - a.NW - a.A - a.NAmax) * a.TSC));
+}
+
+// Build every object's token list once (they are observer independent) and the pattern table.
+// Requires l.ainfo (the map's static assembler info) staged + a barrier before.
+__device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
+  const int* dc = a.dc;
+  const CellCodec cc{a.NW, a.A, a.NAmax};
+  const int4* asm_info = l.ainfo;
+  const int nasm = a.map_nasm[map_id];
+  const int nchest = a.NCmax > 0 ? a.map_nchest[map_id] : 0;
+  const int4* chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+  const int first_chest = a.NW + a.A + a.NAmax;
+  for (int obj = tid; obj < a.NOBJ; obj += nt) {
+    const int ho = mg_heap_off(a, obj);
+    PairOut out{l.heap + ho, 0};
+    if (obj < a.NW + a.A + nasm || (obj >= first_chest && obj < first_chest + nchest))
+      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
+    l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
+  }
+  if (tid == 0) l.ocnt[-1] = 0;  // cell code 0 (empty) looks up "no tokens" without a branch
+  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
+  for (int p = tid; p < P; p += nt) {
+    uint32_t packed = (uint32_t)dc[op + p];
+    int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
+    l.pat[p] = packed | ((uint32_t)(((dr + hr) << 4) | ((dcc + wr) & 0x0F)) << 16);
+  }
+}
+
+struct EncCfg {  // per-kernel constants of the encoder, read from the config stream once (not per agent)
+  int oh, ow, hr, wr, P, T, H, W;
+  uint32_t center;
+  int g_goal, g_compass;
+  uint32_t f_goal, f_compass;
+};
+__device__ inline EncCfg mg_enc_cfg(const KArgs& a) {
+  const int* dc = a.dc;
+  EncCfg c;
+  c.oh = dc[DC_OBS_H]; c.ow = dc[DC_OBS_W]; c.hr = c.oh >> 1; c.wr = c.ow >> 1; c.P = dc[DC_PATTERN_N]; c.T = a.T;
+  c.H = a.H; c.W = a.W;
+  c.center = (uint32_t)((c.hr << 4) | (c.wr & 0x0F));
+  c.g_goal = dc[DC_G_GOAL]; c.g_compass = dc[DC_G_COMPASS];
+  c.f_goal = (uint32_t)dc[DC_FID0 + MG_F_GOAL];
+  c.f_compass = (uint32_t)dc[DC_FID0 + MG_F_COMPASS];
+  return c;
+}
+// The fixed global tokens, one per lane (lane i < n holds the i-th): episode_completion_pct, last_action,
+// last_reward in the reference's order (bindings/mettagrid_c.cpp:416-447).
+struct GlobalTok {
+  int n;
+  uint32_t f, v;
+  bool is_action;
+};
+__device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lane) {
+  const int* dc = a.dc;
+  GlobalTok g;
+  g.f = 0; g.v = 0; g.is_action = false;
+  int n = 0;
+  if (dc[DC_G_COMPLETION]) {
+    const int ms = dc[DC_MAX_STEPS];
+    int pct = 0;
+    if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_COMPLETION]; g.v = (uint32_t)pct; }
+    n++;
+  }
+  if (dc[DC_G_LAST_ACTION]) {
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_LAST_ACTION]; g.is_action = true; }
+    n++;
+  }
+  if (dc[DC_G_LAST_REWARD]) {
+    // rewards are zero whenever observations are computed (zeroed at step start, filled after the encode)
+    if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_LAST_REWARD]; g.v = 0; }
+    n++;
+  }
+  g.n = n;
+  return g;
+}
+
+#define MG_MAX_ROUNDS 4  // ceil(15 * 15 / 64): observation windows are at most 15 x 15
+
+// One agent's observation row, encoded by one wave into `row` (LDS, pre-filled with 0xFF).
+// MettaGrid::_compute_observation (bindings/mettagrid_c.cpp:397-555).  Returns the attempted token count.
+// Window lookups of one agent, all rounds (independent LDS reads: they overlap, and the caller issues them for both
+// agents of a pair before either row is written).  Window offsets never exceed the radius, so "inside the window and
+// the map" is just "inside the map".  meta = heap offset | token count << 16 per window cell.
+template <int NR, bool HOT>
+__device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
+                                                 const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
+                                                 uint32_t& rc) {
+  const int H = ec.H, W = ec.W, P = ec.P;
+  rc = *(const uint32_t*)me;  // r | c << 16 (first two fields of the record)
+  const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    int p = q * 64 + lane;
+    int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
+    const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && (HOT || !(a.diag & 512));
+    // no branches: cells outside the map read cell 0 and are masked; empty cells read the zero entry ocnt[-1]
+    const uint32_t cv = l.grid[ok ? __mul24(r, W) + c : 0];
+    meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];
+  }
+}
+
+template <int NR, bool HOT = false>
+__device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
+                                      const DAgent* me, int action, uint8_t* __restrict__ row,
+                                      const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, const uint32_t (&meta)[NR],
+                                      const uint32_t rc) {
+  const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W;
+  const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
+  // Global tokens at the centre.  The fixed ones (episode completion, last action, last reward) sit one per lane,
+  // prepared once per wave (GlobalTok); goal and compass tokens depend on the agent and follow from lane 0.
+  int base = gt.n;
+  if (lane < gt.n && lane < T) {
+    row[lane * 3 + 0] = (uint8_t)ec.center;
+    row[lane * 3 + 1] = (uint8_t)gt.f;
+    row[lane * 3 + 2] = (uint8_t)(gt.is_action ? action : gt.v);
+  }
+  if ((ec.g_goal || ec.g_compass) && lane == 0) {
+    const uint8_t loc = (uint8_t)ec.center;
+    auto put = [&](uint8_t lc, uint32_t f, int v) {
+      if (base < T) {
+        row[base * 3 + 0] = lc;
+        row[base * 3 + 1] = (uint8_t)f;
+        row[base * 3 + 2] = (uint8_t)v;
+      }
+      base++;
+    };
+    if (ec.g_goal) {
+      const int* dc = a.dc;
+      int og = group_rec(dc, me->group)[GR_OFF_GOAL], ng = L_n(dc, og);
+      for (int i = 0; i < ng; i++) put(loc, ec.f_goal, L_at(dc, og, i));
+    }
+    if (ec.g_compass) {
+      int dr = H / 2 - ar, dcc = W / 2 - ac;
+      int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
+      int orr = hr + sr, occ = wr + sc;
+      if ((sr != 0 || sc != 0) && orr >= 0 && orr < ec.oh && occ >= 0 && occ < ec.ow)
+        put((uint8_t)((orr << 4) | (occ & 0x0F)), ec.f_compass, 1);
+    }
+  }
+  base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int cnt = (int)(meta[q] >> 16);
+    // exclusive prefix sum of cnt over the wave: six DPP steps (row shifts, then the row broadcasts).  (A ballot +
+    // mbcnt count of the single-token objects plus a uniform loop over the multi-token ones cost 4 us more per launch.)
+    int off, total;
+    {
+      int x = cnt;
+      x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+      x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+      x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+      x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+      x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+      x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+      off = x - cnt;
+      total = __builtin_amdgcn_readlane(x, 63);
+    }
+    off += base;
+    if (cnt > 0 && off < T && (HOT || !(a.diag & 128))) {
+      // token lists start 8-byte aligned and are padded to x4 tokens: read 4 tokens per LDS access
+      const uint2* __restrict__ src = (const uint2*)(l.heap + (meta[q] & 0xFFFF));
+      const uint8_t loc = (uint8_t)(pk[q] >> 16);
+      const int n = min(cnt, T - off);
+      uint8_t* __restrict__ dst = row + off * 3;
+      uint2 v = src[0];
+      {  // most objects (walls) have one token: it goes out without any further test
+        const uint32_t t0 = v.x & 0xFFFF;
+        dst[0] = loc; dst[1] = (uint8_t)t0; dst[2] = (uint8_t)(t0 >> 8);
+      }
+      if (n > 1) {
+        for (int k = 0; k < n; k += 4) {
+          if (k) v = src[k >> 2];
+          uint32_t t0 = v.x & 0xFFFF, t1 = v.x >> 16, t2 = v.y & 0xFFFF, t3 = v.y >> 16;
+          if (k) { dst[k * 3 + 0] = loc; dst[k * 3 + 1] = (uint8_t)t0; dst[k * 3 + 2] = (uint8_t)(t0 >> 8); }
+          if (k + 1 < n) { dst[k * 3 + 3] = loc; dst[k * 3 + 4] = (uint8_t)t1; dst[k * 3 + 5] = (uint8_t)(t1 >> 8); }
+          if (k + 2 < n) { dst[k * 3 + 6] = loc; dst[k * 3 + 7] = (uint8_t)t2; dst[k * 3 + 8] = (uint8_t)(t2 >> 8); }
+          if (k + 3 < n) { dst[k * 3 + 9] = loc; dst[k * 3 + 10] = (uint8_t)t3; dst[k * 3 + 11] = (uint8_t)(t3 >> 8); }
+        }
+      }
+    }
+    base += total;
+  }
+  return base;
+}
+
+// All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
+// Requires mg_build_tokens + a barrier before.
+template <int NR, bool PAIRS>
+__device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
+                                       bool write_global, int tid, int nt) {
+  // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
+  // moves to the scalar unit, SGPR spills go from 74 to 99 and the kernel gets slower, 62.5 us against 58.7)
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  uint8_t* rowbuf = l.rows + (size_t)wave * a.ROWB;
+  const int row_bytes = a.T * 3;
+  const EncCfg ec = mg_enc_cfg(a);
+  const GlobalTok gt = mg_global_tok(a, step, lane);
+  uint32_t pk[MG_MAX_ROUNDS];
+#pragma unroll
+  for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q < NR && (q * 64 + lane) < ec.P) ? l.pat[q * 64 + lane] : 0u;
+  // Rows whose length is 8 mod 16 (T = 200: 600 bytes) alternate between phase 0 and 8 in HBM.  A wave then takes
+  // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
+  // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
+  // more than the whole rest of the row).
+  uint8_t* env_obs = a.obs + (size_t)e * a.A * (size_t)row_bytes;
+  const uint32_t env_phase = (uint32_t)(((size_t)e * a.A * (size_t)row_bytes) & 15);
+  constexpr bool pairs = PAIRS;  // write_global && A even && row_bytes % 16 == 8 (checked by the caller)
+  constexpr int group = pairs ? 2 : 1;
+  const int nfill = a.ROWB >> 4;
+  uint2 carry = make_uint2(0, 0);
+  // per-agent offsets are carried along instead of multiplied out (v_mul_lo_u32 runs at quarter rate)
+  uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
+  const DAgent* me0 = l.ag + wave * group;
+  const uint32_t roff_step = (uint32_t)(nwaves * group) * (uint32_t)row_bytes;
+  for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
+  {
+    uint32_t meta[group][NR], rc[group];
+#pragma unroll
+    for (int h = 0; h < group; h++) mg_window_lookup<NR, PAIRS>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
+#pragma unroll
+    for (int h = 0; h < group; h++) {
+      const int ai = a0 + h;
+      // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
+      const uint32_t roff = roff0 + (uint32_t)(h * row_bytes);
+      // paired rows: A * row_bytes is a multiple of 16, the even row starts a chunk, the odd one sits at 8
+      const int phase = PAIRS ? h * 8 : (int)((env_phase + roff) & 15u);
+      uint8_t* row = rowbuf + phase;
+      if (PAIRS || nfill <= 64) {  // the paired shape is only chosen for rows of at most 1024 bytes
+        if (lane < nfill) ((uint4*)rowbuf)[lane] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      } else {
+        for (int i = lane; i < nfill; i += 64) ((uint4*)rowbuf)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+      }
+      if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
+      __builtin_amdgcn_wave_barrier();
+      const int act = exec ? exec[ai] : 0;
+      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, pk, lane, meta[h], rc[h]);
+      if (lane == 0) l.tok_att[ai] = attempted;
+      __builtin_amdgcn_wave_barrier();
+      if (write_global && !(a.diag & 1)) {
+        uint8_t* gbase = env_obs + roff - phase;  // 16-byte aligned (the buffer itself is 256-byte aligned)
+        const int end = phase + row_bytes;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (pairs) {
+          // odd row: the chunk at 0 holds the even row's tail; even row: the tail waits for the odd row.  Every
+          // chunk is full; the rows (at most 1024 bytes in this shape) leave in one store instruction, addressed as
+          // uniform base + 32-bit lane offset.
+          const int nch = (h == 0 ? end - 8 : end) >> 4;
+          if (h == 0) carry = *(const uint2*)(rowbuf + end - 8);
+          if (lane < nch) {
+            const uint4 v = *(const uint4*)(rowbuf + lane * 16);
+            const uint32_t off32 = roff - (uint32_t)phase + (uint32_t)lane * 16u;
+            // streamed out, never re-read by the step kernels: keep it from displacing the map pool and records in L2
+            __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(env_obs + off32));
+          }
+        } else {
+          for (int ch = lane; ch * 16 < end; ch += 64) {
+            const int b0 = ch * 16;
+            if (b0 >= phase && b0 + 16 <= end) {
+              const uint4 v = *(const uint4*)(rowbuf + b0);
+              __builtin_nontemporal_store((u32x4){v.x, v.y, v.z, v.w}, (u32x4*)(gbase + b0));
+            } else {  // the row's ragged head / tail
+              const int lo = b0 < phase ? phase : b0, hi = b0 + 16 < end ? b0 + 16 : end;
+              if (((lo | hi) & 3) == 0) {
+                for (int b = lo; b < hi; b += 4) *(uint32_t*)(gbase + b) = *(const uint32_t*)(rowbuf + b);
+              } else {
+                for (int b = lo; b < hi; b++) gbase[b] = rowbuf[b];
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// The headline shape (window of at most 128 cells, rows of 8 mod 16 bytes in pairs: 11 x 11 window, 200 tokens) has
+// a loop of its own, so that the general loop's state stays out of its registers.
+__device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
+                                     bool write_global, int tid, int nt) {
+  const bool pairs = write_global && (a.A & 1) == 0 && ((a.T * 3) & 15) == 8 && a.ROWB <= 1024;
+  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true>(a, l, e, step, exec, write_global, tid, nt);
+  else mg_encode_all_t<MG_MAX_ROUNDS, false>(a, l, e, step, exec, write_global, tid, nt);  // any shape
+}
+
+// Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
+// so that rounding above 2^24 matches the reference.  Thread 0 only.
+__device__ inline void mg_token_stats(const KArgs& a, const Lds& l, int passes) {
+  float w = l.tokacc[0], d = l.tokacc[1], f = l.tokacc[2];
+  for (int p = 0; p < passes; p++)
+    for (int i = 0; i < a.A; i++) {
+      int att = l.tok_att[i];
+      int wr = att < a.T ? att : a.T;
+      w += (float)wr;
+      d += (float)(att - wr);
+      f += (float)(a.T - wr);
+    }
+  l.tokacc[0] = w;
+  l.tokacc[1] = d;
+  l.tokacc[2] = f;
+}
+
+// Fresh episode state in LDS + zeroed global stats (MettaGrid ctor: bindings/mettagrid_c.cpp:46-155,159-245).
+__device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e, int map_id, uint32_t seed, int tid,
+                                    int nt) {
+  const int* dc = a.dc;
+  const int4* spawn = a.map_spawn + (size_t)map_id * a.A;
+  for (int i = tid; i < a.A; i += nt) {
+    int4 s = spawn[i];
+    DAgent ag;
+    memset(&ag, 0, sizeof(ag));
+    ag.r = ag.prev_r = (uint16_t)s.x;
+    ag.c = ag.prev_c = (uint16_t)s.y;
+    ag.group = (uint8_t)s.z;
+    ag.vibe = (uint8_t)group_rec(dc, s.z)[GR_INITIAL_VIBE];
+    ag.nb = 1;
+    l.ag[i] = ag;
+  }
+  int nasm = a.map_nasm[map_id];
+  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  for (int i = tid; i < a.NAmax; i += nt) {
+    DAsm s = {0, 0, 0, 0};
+    if (i < nasm) s.clipped = (uint32_t)asm_rec(dc, asm_info[i].z)[AR_START_CLIPPED];
+    l.as[i] = s;
+  }
+  for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  for (int i = tid; i < a.A; i += nt) {
+    l.dirty_amt[i] = 0;
+    l.dirty_misc[i] = 0;
+  }
+  // zero the running-episode stats in HBM
+  float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  for (int i = tid; i < a.A * a.SA; i += nt) as_[i] = 0.f;
+  uint32_t* at_ = a.atouched + (size_t)e * a.A * a.TW;
+  for (int i = tid; i < a.A * a.TW; i += nt) at_[i] = 0u;
+  float* gs_ = a.gstats + (size_t)e * a.SG;
+  uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.GW; i += nt) gt_[i] = 0u;
+  __syncthreads();
+  // objects.<cell name> counts (bindings/mettagrid_c.cpp:203,224,235)
+  const float* oc = a.map_objcount + (size_t)map_id * a.n_cells;
+  for (int i = tid; i < a.SG; i += nt) {
+    float v = 0.f;
+    int code = i - 3 + 1;
+    if (code >= 1 && code < a.n_cells && oc[code] > 0.f) {
+      v = oc[code];
+      atomicOr(&gt_[i >> 5], 1u << (i & 31));
+    }
+    gs_[i] = v;
+  }
+  for (int i = tid; i < a.A; i += nt) {
+    size_t g = (size_t)e * a.A + i;
+    a.rewards[g] = 0.f;
+    a.ep_rewards[g] = 0.f;
+    a.term[g] = 0;
+    a.trunc[g] = 0;
+    a.success[g] = 0;
+  }
+  if (tid == 0) {
+    l.tokacc[0] = l.tokacc[1] = l.tokacc[2] = 0.f;
+    // std::mt19937(seed): mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i
+    uint32_t* mt = a.mt + (size_t)e * 624;
+    uint32_t* mi = a.mt_init ? a.mt_init + (size_t)e * 624 : mt;
+    uint32_t x = seed;
+    mt[0] = x;
+    mi[0] = x;
+    for (int i = 1; i < 624; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      mt[i] = x;
+      mi[i] = x;
+    }
+  }
+  // populate_initial_inventory (agent.cpp:48-52): ignore_limits, stat hooks fire; one thread per agent
+  for (int i = tid; i < a.A; i += nt) {
+    const int* gr = group_rec(dc, l.ag[i].group);
+    int oi = gr[GR_OFF_INITIAL], n = L_n(dc, oi);
+    for (int k = 0; k < n; k++) inv_update(cx, i, KV_k(dc, oi, k), KV_v(dc, oi, k), true);
+  }
+  // chests (chest.hpp:83-87): initial inventory, positive amounts only, limits ignored.  One thread, map order: the
+  // chest.<r>.amount game stat is a `set`, the last chest holding <r> wins.
+  if (tid == 0) {
+    *l.gsetm = 0;
+    const int nchest = a.NCmax > 0 ? a.map_nchest[map_id] : 0;
+    const int4* chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+    for (int ci = 0; ci < a.NCmax; ci++) {
+      DAgent rec;
+      memset(&rec, 0, sizeof(rec));
+      rec.nb = 1;
+      if (ci < nchest) {
+        const int4 info = chest_info[ci];
+        rec.r = rec.prev_r = (uint16_t)info.x;
+        rec.c = rec.prev_c = (uint16_t)info.y;
+        rec.group = (uint8_t)(dc + dc[dc[DC_OFF_CHESTS] + info.z])[CR_GROUP];
+      }
+      l.ch[ci] = rec;
+      if (ci < nchest) {
+        const int oi = group_rec(dc, rec.group)[GR_OFF_INITIAL], n = L_n(dc, oi);
+        for (int k = 0; k < n; k++)
+          if (KV_v(dc, oi, k) > 0) inv_update(cx, a.A + ci, KV_k(dc, oi, k), KV_v(dc, oi, k), true);
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+// Push this step's stat deltas to HBM and mark touched keys.
+__device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& cx, int e, int tid, int nt) {
+  float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  uint32_t* at_ = a.atouched + (size_t)e * a.A * a.TW;
+  for (int ai = tid; ai < a.A; ai += nt) {
+    uint32_t m = l.dirty_amt[ai];
+    while (m) {
+      int r = __ffs(m) - 1;
+      m &= m - 1;
+      int s = cx.AS.amount(r);
+      as_[ai * a.SA + s] = (float)l.ag[ai].amt[r];
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+    uint32_t dm = l.dirty_misc[ai];
+    if (dm & 1u) {
+      int s = cx.AS.diversity();
+      as_[ai * a.SA + s] = (float)l.ag[ai].diversity;
+      atomicOr(&at_[ai * a.TW + (s >> 5)], 1u << (s & 31));
+    }
+  }
+  float* gs_ = a.gstats + (size_t)e * a.SG;
+  uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.SG; i += nt) {
+    int v = l.gd[i];
+    if (v != 0) {
+      gs_[i] += (float)v;
+      atomicOr(&gt_[i >> 5], 1u << (i & 31));
+    }
+  }
+  if (a.NCmax > 0 && tid < a.R && ((*l.gsetm >> tid) & 1u)) {  // StatsTracker::set of chest.<r>.amount
+    const int s = cx.GS.chest_amount(tid);
+    gs_[s] = (float)l.gsetv[tid];
+    atomicOr(&gt_[s >> 5], 1u << (s & 31));
+  }
+}
+
+// Agent::compute_stat_rewards (agent.cpp:103-132) + episode bookkeeping (bindings/mettagrid_c.cpp:656-677).
+__device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e, DEnv env, int tid, int nt) {
+  const int* dc = a.dc;
+  const MgAgentSlots AS{a.R, a.NG};
+  bool end_now = false, trunc_now = false;
+  {
+    int ms = dc[DC_MAX_STEPS];
+    if (ms > 0 && env.step >= (uint32_t)ms) {
+      end_now = true;
+      trunc_now = dc[DC_TRUNCATES] != 0;
+    }
+  }
+  bool early = env.early_reset != 0 && env.step >= env.early_reset;
+  const float* as_ = a.astats + (size_t)e * a.A * a.SA;
+  const float* gs_ = a.gstats + (size_t)e * a.SG;
+  for (int ai = tid; ai < a.A; ai += nt) {
+    DAgent* me = &l.ag[ai];
+    const int* gr = group_rec(dc, me->group);
+    int os = gr[GR_OFF_STAT_REWARDS], ns = dc[os];
+    float reward = 0.f;
+    size_t g = (size_t)e * a.A + ai;
+    if (ns > 0) {
+      float total = 0.f;
+      for (int q = 0; q < ns; q++) {
+        const int* sr = dc + os + 1 + 5 * q;
+        int aslot = sr[0], gslot = sr[1];
+        float v = 0.f;
+        if (aslot >= 0) {
+          if (aslot >= AS.amount(0) && aslot < AS.amount(0) + a.R)
+            v = (float)me->amt[aslot - AS.amount(0)];
+          else if (aslot == AS.max_steps_without_motion())
+            v = (float)me->max_swm;
+          else if (aslot == AS.diversity())
+            v = (float)me->diversity;
+          else if (aslot < 3)
+            v = (float)me->succ[aslot];
+          else if (aslot < 6)
+            v = (float)me->fail[aslot - 3];
+          else if (aslot == AS.failed_any())
+            v = (float)(me->fail[0] + me->fail[1] + me->fail[2]);
+          else
+            v = as_[ai * a.SA + aslot];
+        }
+        if (gslot >= 0) v += gslot < 3 ? l.tokacc[gslot] : gs_[gslot];
+        float rew = v * __int_as_float(sr[2]);
+        if (sr[3]) {
+          float mx = __int_as_float(sr[4]);
+          rew = (mx < rew) ? mx : rew;
+        }
+        total += rew;
+      }
+      float delta = total - me->cur_reward;
+      if (delta != 0.0f) {
+        reward = delta;
+        me->cur_reward = total;
+        a.agents[g].cur_reward = total;
+      }
+    }
+    a.rewards[g] = reward;
+    a.ep_rewards[g] += reward;
+    if (end_now) {
+      if (trunc_now) a.trunc[g] = 1; else a.term[g] = 1;
+    }
+    if (early) a.trunc[g] = 1;
+  }
+  if (tid == 0 && (end_now || early)) {
+    a.env[e].done = 1;
+    if (early) a.env[e].early_reset = 0;
+  }
+}
+
+__device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e, int map_id, uint32_t step) {
+  cx.dc = a.dc;
+  cx.grid = l.grid;
+  cx.ag = l.ag;
+  cx.as = l.as;
+  cx.asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  cx.astats = a.astats + (size_t)e * a.A * a.SA;
+  cx.atouched = a.atouched + (size_t)e * a.A * a.TW;
+  cx.TW = a.TW;
+  cx.gd = l.gd;
+  cx.dirty_amt = l.dirty_amt;
+  cx.tmp = l.tmp;
+  cx.dirty_misc = l.dirty_misc;
+  cx.H = a.H; cx.W = a.W; cx.A = a.A; cx.NA = a.NAmax; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG;
+  cx.step = step;
+  cx.asm_dirty = 0;
+  cx.AS = MgAgentSlots{a.R, a.NG};
+  cx.GS = MgGameSlots{a.R, a.n_cells - 1};
+  cx.cc = CellCodec{a.NW, a.A, a.NAmax};
+  cx.ch = l.ch;
+  cx.chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+  cx.NC = a.NCmax;
+  cx.gsetv = l.gsetv;
+  cx.gsetm = l.gsetm;
+  cx.overflow = 0;
+}
+
+// Cooperative copy of `bytes` (a multiple of 4) between HBM arrays: 16 bytes per lane and several loads in flight
+// when the alignment allows (restarts sit on the critical path of the act kernels).
+__device__ inline void mg_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes, int tid, int nt) {
+  if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 15) == 0) {
+    const uint4* __restrict__ s = (const uint4*)src;
+    uint4* __restrict__ d = (uint4*)dst;
+    const int n = (int)(bytes >> 4);
+    int i = tid;
+    for (; i + 3 * nt < n; i += 4 * nt) {
+      uint4 v0 = s[i], v1 = s[i + nt], v2 = s[i + 2 * nt], v3 = s[i + 3 * nt];
+      d[i] = v0; d[i + nt] = v1; d[i + 2 * nt] = v2; d[i + 3 * nt] = v3;
+    }
+    for (; i < n; i += nt) d[i] = s[i];
+  } else {
+    const uint32_t* __restrict__ s = (const uint32_t*)src;
+    uint32_t* __restrict__ d = (uint32_t*)dst;
+    const int n = (int)(bytes >> 2);
+    for (int i = tid; i < n; i += nt) d[i] = s[i];
+  }
+}
+
+// Keep the finished episode's stats for the host and add it to the device-wide summary.
+__device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t steps, int tid, int nt) {
+  size_t na = (size_t)a.A * a.SA, nta = (size_t)a.A * a.TW;
+  float* fas = a.fin_astats + (size_t)e * na;
+  mg_copy(fas, a.astats + (size_t)e * na, na * 4, tid, nt);
+  mg_copy(a.fin_atouched + (size_t)e * nta, a.atouched + (size_t)e * nta, nta * 4, tid, nt);
+  __syncthreads();
+  {  // merge the record-resident counters into the finished snapshot
+    const MgAgentSlots AS{a.R, a.NG};
+    for (int ai = tid; ai < a.A; ai += nt) {
+      const DAgent* ag = &a.agents[(size_t)e * a.A + ai];
+      float* row = fas + (size_t)ai * a.SA;
+      uint32_t fa = 0;
+      for (int h = 0; h < 3; h++) {
+        row[AS.success(h)] = (float)ag->succ[h];
+        row[AS.failed(h)] = (float)ag->fail[h];
+        fa += ag->fail[h];
+      }
+      row[AS.failed_any()] = (float)fa;
+      row[AS.max_steps_without_motion()] = (float)ag->max_swm;
+    }
+  }
+  const float* gs_ = a.gstats + (size_t)e * a.SG;
+  float* fgs = a.fin_gstats + (size_t)e * a.SG;
+  for (int i = tid; i < a.SG; i += nt) {
+    float v = gs_[i];
+    fgs[i] = v;
+    if (v != 0.f) atomicAdd(&a.summary[3 + i], (double)v);
+  }
+  const uint32_t* gt_ = a.gtouched + (size_t)e * a.GW;
+  uint32_t* fgt = a.fin_gtouched + (size_t)e * a.GW;
+  for (int i = tid; i < a.GW; i += nt) fgt[i] = gt_[i];
+  for (int i = tid; i < a.A; i += nt) {
+    float r = a.ep_rewards[(size_t)e * a.A + i];
+    a.fin_ep_rewards[(size_t)e * a.A + i] = r;
+    if (r != 0.f) atomicAdd(&a.summary[2], (double)r);
+  }
+  if (tid == 0) {
+    a.fin_steps[e] = steps;
+    atomicAdd(&a.status[1], 1u);
+    atomicAdd(&a.summary[0], 1.0);
+    atomicAdd(&a.summary[1], (double)steps);
+  }
+}
+
+// Stage the window of MT19937 outputs this step may consume; twist cooperatively when it crosses the block end.
+__device__ inline void mg_stage_rng(const KArgs& a, const Lds& l, int e, uint32_t mt_idx, int tid, int nt) {
+  const uint32_t* mt = a.mt + (size_t)e * 624;
+  bool need_twist = (int)mt_idx + a.NWIN > 624;  // block-uniform
+  if (need_twist) {
+    for (int i = tid; i < 227; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+    __syncthreads();
+    for (int i = 227 + tid; i < 454; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+    __syncthreads();
+    for (int i = 454 + tid; i < 623; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+    __syncthreads();
+    if (tid == 0) l.mtnext[623] = mt_mix(mt[623], l.mtnext[0], l.mtnext[396]);
+    __syncthreads();
+  }
+  for (int i = tid; i < a.NWIN; i += nt) {
+    int j = (int)mt_idx + i;
+    uint32_t raw = j < 624 ? mt[j] : l.mtnext[(j - 624) % 624];
+    l.win[i] = mt_temper(raw);
+  }
+}
+
+// Restart a finished environment from the per-map templates (MettaGridPufferEnv.step -> _new_sim(),
+// mettagrid_puffer_env.py:158-164; same seed, next map).  All threads of the workgroup; HBM state only.
+__device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid, int nt) {
+  mg_snapshot_finished(a, e, env.step, tid, nt);
+  __syncthreads();
+  const int m = (int)(((int)env.map_id + a.map_stride) % a.P);
+  env.map_id = (uint32_t)m;
+  env.episodes += 1;
+  env.step = 0;
+  env.mt_idx = 624;
+  env.done = 0;
+  env.early_reset = 0;  // EarlyResetHandler cuts the first episode only
+  mg_copy(a.agents + (size_t)e * a.A, a.t_agents + (size_t)m * a.A, (size_t)a.A * sizeof(DAgent), tid, nt);
+  mg_copy(a.asms + (size_t)e * a.NAmax, a.t_asms + (size_t)m * a.NAmax, (size_t)a.NAmax * sizeof(DAsm), tid, nt);
+  if (a.NCmax > 0)
+    mg_copy(a.chests + (size_t)e * a.NCmax, a.t_chests + (size_t)m * a.NCmax, (size_t)a.NCmax * sizeof(DAgent), tid, nt);
+  mg_copy(a.astats + (size_t)e * a.A * a.SA, a.t_astats + (size_t)m * a.A * a.SA, (size_t)a.A * a.SA * 4, tid, nt);
+  mg_copy(a.atouched + (size_t)e * a.A * a.TW, a.t_atouched + (size_t)m * a.A * a.TW, (size_t)a.A * a.TW * 4, tid, nt);
+  mg_copy(a.gstats + (size_t)e * a.SG, a.t_gstats + (size_t)m * a.SG, (size_t)a.SG * 4, tid, nt);
+  mg_copy(a.gtouched + (size_t)e * a.GW, a.t_gtouched + (size_t)m * a.GW, (size_t)a.GW * 4, tid, nt);
+  mg_copy(a.mt + (size_t)e * 624, a.mt_init + (size_t)e * 624, 624 * 4, tid, nt);
+  for (int i = tid; i < a.A; i += nt) {
+    size_t g = (size_t)e * a.A + i;
+    a.rewards[g] = 0.f;
+    a.ep_rewards[g] = 0.f;
+    a.term[g] = 0;
+    a.trunc[g] = 0;
+    a.success[g] = 0;
+  }
+  __threadfence();
+  __syncthreads();
+}
+
+
+// ---- launchers (one per kernel translation unit) ---------------------------------------------------------------
+#define MG_FAST_THREADS 64
+#define MG_USES_THREADS 64
+#define MG_ACT_THREADS 64
+void mg_launch_act_fast(const KArgs& k, unsigned n, hipStream_t st);                                   // k_act_fast.hip
+void mg_launch_uses(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);                // k_uses.hip
+void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_act.hip
+void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_obs.hip
+void mg_launch_reset(const KArgs& k, unsigned n, size_t lds, bool big, hipStream_t st);               // k_reset.hip
+// the cap on dynamic LDS is a per-function setting shared by every handle of the process
+hipError_t mg_raise_lds_cap_uses(int cap);
+hipError_t mg_raise_lds_cap_act(int cap);
+hipError_t mg_raise_lds_cap_obs(int cap);
+hipError_t mg_raise_lds_cap_reset(int cap);
