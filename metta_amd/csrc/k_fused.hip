@@ -1,0 +1,613 @@
+// k_fused.hip -- the whole step of one environment in ONE workgroup of two waves (attack-free configurations, A <= 64:
+// arena, navigation).  Replaces the three launches mg_act_fast_kernel -> mg_uses_kernel -> mg_obs_kernel:
+//
+//   P0  both waves   env words, episode restart (rare), stage the config prefix, the agent records and the MT19937
+//                    window into LDS -- every load is issued before the first wait
+//   P1  one wave     the reference's shuffled sequential action loop, lane = agent (mettagrid_c.cpp:588-622): shuffle
+//                    ranks from the same MT19937 draws, move resolution as a fixed point over ballots, assembler uses
+//                    collected in rank order with the neighbour ring as it stood at that turn
+//   P2  one wave     the assembler uses (assembler.hpp:455-526) on the LDS records; independent uses on separate lanes
+//   P3  both waves   per-object token lists, observation rows (mettagrid_c.cpp:397-555), tokens_* stats, stat rewards,
+//                    episode flags (:652-677); the records go back to HBM once
+//
+// A step of one environment is a chain of dependent phases, most of them latency bound; what hides the latency is the
+// number of environments resident on a CU.  The kernel is therefore built around its LDS footprint: about 10 KB per
+// environment (arena), so that 16 workgroups x 2 waves fill a CU (32 waves, 160 KB) and 4096 environments are resident
+// on the chip at once.  To get there nothing that other workgroups can share is copied into LDS: the static map layer
+// is read from the byte pool in HBM/L2 (window lookups, move targets) and the agents are scattered over the window
+// through a 128-byte per-wave buffer; assembler records and the map's assembler table are used in place in HBM; only
+// the prefix of the config stream that the use / token code walks with dependent reads is staged.
+// Against the three-kernel path the agent records are read and written once instead of three times, and the hand-over
+// buffers (mode / pending uses / executed action) never leave LDS.
+#include "mg_kernels.h"
+
+// Built twice: as is, and through k_fused_nomod.hip with MG_NO_MODIFIERS (configurations without inventory-limit
+// modifiers, e.g. arena and navigation: the use code then needs far fewer registers).
+#ifdef MG_NO_MODIFIERS
+#define mg_step_fused_kernel mg_step_fused_nomod_kernel
+#define mg_launch_fused mg_launch_fused_nomod
+#define mg_fused_lds_bytes mg_fused_lds_bytes_nomod
+#define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod
+#endif
+#define MG_FUSED_THREADS 128
+#define MG_FUSED_SLOTS 4  // assembler uses resolved concurrently (scratch slots of 96 ints)
+
+template <bool FILL>
+__host__ __device__ inline size_t mg_carve_fused(unsigned char* base, Lds* l, int A, int SG, int ROWB, int nwaves, int dcw,
+                                                 int NOBJ, int HEAP, int NP) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4);
+  size_t ag = take((size_t)A * sizeof(DAgent));
+  // row buffers (encode) <- aliases -> pending assembler uses (P1-P2)
+  size_t rows_b = (size_t)ROWB * nwaves;
+  if (rows_b < (size_t)A * 32) rows_b = (size_t)A * 32;
+  size_t rows = take(rows_b);
+  // token lists + per-object counts (P3) <- aliases -> use scratch (P2) <- aliases -> next MT19937 block (P0-P1)
+  size_t oc_b = mg_align16((size_t)(NOBJ + 1) * 4), hp_b = mg_align16((size_t)HEAP * 2);
+  size_t u_b = oc_b + hp_b;
+  if (u_b < (size_t)MG_FUSED_SLOTS * 96 * 4) u_b = (size_t)MG_FUSED_SLOTS * 96 * 4;
+  if (u_b < 624 * 4) u_b = 624 * 4;
+  size_t u = take(u_b);
+  const int WS = (NP + 63) & ~63;
+  size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP);
+  size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16);
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A);
+  size_t fl = take(32), su = take((size_t)A);
+  if (FILL) {
+    l->dc = (int*)(base + dco);
+    l->grid = nullptr; l->ag = (DAgent*)(base + ag); l->ch = l->ag + A;
+    l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
+    l->rows = (uint8_t*)(base + rows); l->pend = base + rows;
+    l->ocnt = (uint32_t*)(base + u) + 1; l->heap = (uint16_t*)(base + u + oc_b); l->pat = nullptr;
+    l->tmp = (int*)(base + u); l->mtnext = (uint32_t*)(base + u);
+    l->wscr = base + ws; l->ipat = base + ip; l->WS = WS;
+    l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
+    l->order = (uint16_t*)(base + ord); l->flags = (int*)(base + fl); l->succ = base + su;
+    l->gsetv = nullptr; l->gsetm = nullptr; l->win = nullptr;
+  }
+  return o;
+}
+
+// ---- P1: the action phase of mg_act_fast_kernel on LDS-staged state (wave 0, lane = agent) ---------------------------
+// `act` = this lane's action, `w` = tempered MT19937 output mt_idx + lane.  Returns the MT outputs consumed; sets
+// *n_pending_out (wave-uniform) and env.error bits.
+__device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, DEnv& env, const int lane, const int act,
+                                                 const uint32_t w, const int NW_, int* n_pending_out) {
+  const int A = a.A;
+  const int* dc = a.dc;
+  const bool active = lane < A;
+  const int H = a.H, W = a.W;
+  DAgent* rec = l.ag + (active ? lane : 0);
+  uint4 f0 = make_uint4(0, 0, 0, 0);
+  uint32_t max_swm = 0;
+  if (active) {
+    f0 = *(const uint4*)rec;
+    max_swm = rec->max_swm;
+  }
+  int r = (int)(f0.x & 0xFFFF), c = (int)(f0.x >> 16);
+  const int frozen = (int)(int16_t)(f0.z & 0xFFFF);
+  uint32_t vibe = (f0.z >> 16) & 0xFF, swm = f0.w;
+  // Eligible configurations have no attacks, so nothing can freeze an agent; flag it loudly if it ever happens.
+  if (__ballot(active && frozen != 0) != 0) env.error |= 4u;
+
+  // draw t of std::shuffle(iota(A)): t = 0 -> U(2) when A is even; then positions i = i0 + 2(t - t0), range (i+1)(i+2)
+  const int even = (A & 1) == 0 ? 1 : 0;
+  const int D = A <= 1 ? 0 : even + (A - (even ? 2 : 1)) / 2;
+  uint32_t val = 0;
+  bool reject = false;
+  if (lane < D) {
+    uint32_t range;
+    if (even && lane == 0) {
+      range = 2;
+    } else {
+      uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (lane - even));
+      range = (i + 1) * (i + 2);
+    }
+    unsigned long long product = (unsigned long long)w * range;
+    uint32_t low = (uint32_t)product;
+    reject = low < range && low < (0u - range) % range;  // Lemire rejection: extremely rare, needs a serial redraw
+    val = (uint32_t)(product >> 32);
+  }
+  uint32_t used = (uint32_t)D;  // MT19937 outputs consumed by the shuffle
+  if (__ballot(reject) != 0 || (a.diag & 8)) {
+    // A rejected draw shifts every later draw by one output: redo the draws one after the other (wave-uniform scalars;
+    // about one step in a million takes this branch, MG_DIAG bit 8 forces it for the tests).
+    int idx = 0;
+    bool overflow = false;
+    for (int t = 0; t < D; t++) {
+      uint32_t range = 2;
+      if (!(even && t == 0)) {
+        const uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (t - even));
+        range = (i + 1) * (i + 2);
+      }
+      const uint32_t threshold = (0u - range) % range;
+      uint32_t hi = 0;
+      for (;;) {
+        if (idx >= NW_) {
+          overflow = true;
+          break;
+        }
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readlane((int)w, idx);
+        idx++;
+        const unsigned long long product = (unsigned long long)wv * range;
+        const uint32_t low = (uint32_t)product;
+        hi = (uint32_t)(product >> 32);
+        if (!(low < range && low < threshold)) break;
+      }
+      if (lane == t) val = hi;
+    }
+    used = (uint32_t)idx;
+    if (overflow) env.error |= 1u;
+  }
+  // ranks: agent x sits at position rank_x of the shuffled order; a swap of positions (p, q) exchanges the ranks.
+  int pa_l = 0, pb_l = 0;
+  if (lane < D && !(even && lane == 0)) {
+    const uint32_t s1 = (uint32_t)((even ? 2 : 1) + 2 * (lane - even)) + 2u;  // s + 1
+    pa_l = (int)(val / s1);
+    pb_l = (int)(val - (uint32_t)pa_l * s1);
+  }
+  int rank = lane;
+  for (int t = 0; t < D; t++) {
+    if (even && t == 0) {
+      int j = __builtin_amdgcn_readlane((int)val, 0);  // swap(v[1], v[j])
+      rank = rank == 1 ? j : (rank == j ? 1 : rank);
+    } else {
+      int i = (even ? 2 : 1) + 2 * (t - even);
+      int pa = __builtin_amdgcn_readlane(pa_l, t), pb = __builtin_amdgcn_readlane(pb_l, t);
+      rank = rank == i ? pa : (rank == pa ? i : rank);
+      rank = rank == i + 1 ? pb : (rank == pb ? i + 1 : rank);
+    }
+  }
+
+  // ---- decode actions ------------------------------------------------------------------------------------
+  const int n_actions = dc[DC_N_ACTIONS], oa = dc[DC_OFF_ACTIONS];
+  const bool valid = active && act >= 0 && act < n_actions;
+  int kind = -1, arg = 0;
+  if (valid) {  // (the action table lies behind the LDS-staged prefix of the stream)
+    const int2 ka = *(const int2*)(a.gdc + oa + 2 * act);
+    kind = ka.x;
+    arg = ka.y;
+  }
+  const bool is_move = valid && kind == MG_ACT_MOVE;
+  const bool is_vibe = valid && kind == MG_ACT_CHANGE_VIBE;
+  int tr = r, tc = c;
+  uint16_t scell = 0;
+  bool inb = false;
+  if (is_move) {
+    // deltas of orientation.hpp:26-48: N S W E NW NE SW SE
+    const int dx = (arg == 2 || arg == 4 || arg == 6) ? -1 : ((arg == 3 || arg == 5 || arg == 7) ? 1 : 0);
+    const int dy = (arg == 0 || arg == 4 || arg == 5) ? -1 : ((arg == 1 || arg == 6 || arg == 7) ? 1 : 0);
+    tr = r + dy;
+    tc = c + dx;
+    inb = tr >= 0 && tc >= 0 && tr < H && tc < W;
+    if (inb) scell = (uint16_t)l.gmap[tr * W + tc];  // the static layer of the map (HBM pool, L2)
+  }
+  const CellCodec cc{a.NW, A, a.NAmax};
+  const int skind = cc.kind(scell);
+  const bool mover = is_move && inb && skind == MG_CELL_EMPTY;
+  const bool user = is_move && inb && skind == MG_CELL_ASSEMBLER;
+  const uint32_t P = ((uint32_t)r << 16) | (uint32_t)c;
+  const uint32_t Tm = mover ? (((uint32_t)tr << 16) | (uint32_t)tc) : 0xFFFFFFFFu;
+
+  // ---- fixed point over move success ----------------------------------------------------------------------
+  unsigned long long occ = 0, tgt = 0, lower = 0;
+  for (int j = 0; j < A; j++) {
+    const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
+    const uint32_t Tj = (uint32_t)__builtin_amdgcn_readlane((int)Tm, j);
+    const int rj = __builtin_amdgcn_readlane(rank, j);
+    const unsigned long long bit = 1ull << j;
+    if (Pj == Tm) occ |= bit;
+    if (Tj == Tm && j != lane) tgt |= bit;
+    if (rj < rank) lower |= bit;
+  }
+  bool m = mover;
+  for (int it = 0; it <= A; it++) {
+    const unsigned long long before = lower & __ballot(m);  // moved (away / in) before my turn
+    const bool nm = mover && (occ & ~before) == 0 && (tgt & before) == 0;
+    const bool changed = nm != m;
+    m = nm;
+    if (__ballot(changed) == 0) break;
+  }
+
+  // ---- assembler uses, in rank order, with the ring as it stood at that moment ------------------------------
+  unsigned long long umask = __ballot(user);
+  int n_pending = 0;
+  uint8_t* pend = l.pend;
+  while (umask) {
+    int best = -1, best_rank = 1 << 30;
+    unsigned long long scan = umask;
+    while (scan) {
+      int j = __ffsll((long long)scan) - 1;
+      scan &= scan - 1;
+      int rj = __builtin_amdgcn_readlane(rank, j);
+      if (rj < best_rank) {
+        best_rank = rj;
+        best = j;
+      }
+    }
+    umask &= ~(1ull << best);
+    const int k = best_rank;
+    const int ar = __builtin_amdgcn_readlane(tr, best), ac = __builtin_amdgcn_readlane(tc, best);
+    const int asm_cell = __builtin_amdgcn_readlane((int)scell, best);
+    const int uact = __builtin_amdgcn_readlane(act, best);
+    const bool before = rank < k;
+    const int pr = (before && m) ? tr : r, pc = (before && m) ? tc : c;
+    const uint32_t vk = (before && is_vibe) ? (uint32_t)arg : vibe;
+    const int dr = pr - ar, dcl = pc - ac;
+    const bool adj = active && dr >= -1 && dr <= 1 && dcl >= -1 && dcl <= 1 && !(dr == 0 && dcl == 0);
+    uint32_t vmask8 = 0;
+    for (int q = 0; q < 8; q++) {
+      int o9 = q < 4 ? q : q + 1;
+      int rr = ar + o9 / 3 - 1, c2 = ac + o9 % 3 - 1;
+      if (rr >= 0 && c2 >= 0 && rr < H && c2 < W) vmask8 |= 1u << q;
+    }
+    const int np = __popc(vmask8);
+    int o9m = (dr + 1) * 3 + (dcl + 1);
+    int om = o9m < 4 ? o9m : o9m - 1;
+    int posidx = adj ? __popc(vmask8 & ((1u << om) - 1u)) : 0;
+    const int start = __builtin_amdgcn_readlane(posidx, best);  // the actor is adjacent by construction
+    int key = adj ? (posidx - start + np) % np : -1;
+    uint8_t* rec8 = pend + (size_t)n_pending * 32;
+    int nn = 0;
+    for (int q = 0; q < np; q++) {
+      unsigned long long sel = __ballot(adj && key == q);
+      if (sel) {
+        int j = __ffsll((long long)sel) - 1;
+        uint32_t vj = (uint32_t)__builtin_amdgcn_readlane((int)vk, j);
+        if (lane == 0) {
+          rec8[8 + nn] = (uint8_t)j;
+          rec8[16 + nn] = (uint8_t)vj;
+        }
+        nn++;
+      }
+    }
+    if (lane == 0) {
+      rec8[0] = (uint8_t)best;
+      rec8[1] = (uint8_t)nn;
+      int ai_ = cc.asm_idx((uint16_t)asm_cell);
+      rec8[2] = (uint8_t)(ai_ & 0xFF);
+      rec8[3] = (uint8_t)(ai_ >> 8);
+      *(int*)(rec8 + 4) = uact;
+    }
+    n_pending++;
+  }
+
+  // ---- per-agent bookkeeping (action_handler.hpp:118-150) ----------------------------------------------------
+  if (active) {
+    bool ok = false;
+    if (valid) {
+      if (kind == MG_ACT_NOOP) ok = true;
+      else if (is_vibe) { vibe = (uint32_t)arg; ok = true; }
+      else if (mover) ok = m;
+      if (m) { r = tr; c = tc; swm = 0; }
+      else { swm += 1; if (swm > max_swm) max_swm = swm; }
+      if (!user) {  // users: success / failure is decided by the use itself (P2)
+        if (ok) rec->succ[kind] += 1;
+        else rec->fail[kind] += 1;
+      }
+      f0.x = ((uint32_t)c << 16) | (uint32_t)r;
+      f0.y = f0.x;  // prev_location = location
+      f0.z = (f0.z & 0xFF00FFFFu) | (vibe << 16);
+      f0.w = swm;
+      *(uint4*)rec = f0;
+      rec->max_swm = max_swm;
+    } else {
+      // _handle_invalid_action, once per priority level (bindings/mettagrid_c.cpp:565-570,599-608).  Atomic adds like
+      // every other direct stat update of this launch (small integers: exact and order independent).
+      const MgAgentSlots AS{a.R, a.NG};
+      const int passes = dc[DC_MAX_PRIORITY] + 1;
+      float* row = a.astats + ((size_t)(blockIdx.x + a.env_base) * A + lane) * a.SA;
+      int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
+      atomicAdd(&row[AS.invalid()], (float)passes);
+      atomicAdd(&row[AS.invalid_variant(variant)], (float)passes);
+    }
+    l.exec[lane] = ok ? act : 0;
+    l.succ[lane] = ok ? 1 : 0;
+  }
+  *n_pending_out = n_pending;
+  return used;
+}
+
+// ---- P2: assembler uses in action order, independent ones on separate lanes (wave 0 only; no workgroup barrier) -------
+#ifndef MG_FUSED_USES_ATTR
+#define MG_FUSED_USES_ATTR __forceinline__
+#endif
+__device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, Ctx& cx, const int count, const int lane) {
+  const uint8_t* recs = l.pend;
+  uint8_t* rounds = (uint8_t*)l.order;  // [A] bytes
+  // round of use q = 1 + the latest round among earlier uses that share an agent or the assembler with it
+  if (count == 1) {
+    if (lane == 0) {
+      rounds[0] = 0;
+      l.flags[0] = 0;
+      l.flags[2] = 0;
+    }
+  } else if (lane == 0) {
+    int max_round = 0;
+    for (int q = 0; q < count; q++) {
+      const uint8_t* rq = recs + q * 32;
+      unsigned long long mq = 0;
+      for (int i = 0; i < rq[1]; i++) mq |= 1ull << rq[8 + i];
+      int aq = rq[2] | (rq[3] << 8), rd = 0;
+      for (int p2 = 0; p2 < q; p2++) {
+        const uint8_t* rp = recs + p2 * 32;
+        unsigned long long mp = 0;
+        for (int i = 0; i < rp[1]; i++) mp |= 1ull << rp[8 + i];
+        int ap = rp[2] | (rp[3] << 8);
+        if ((mp & mq) != 0 || ap == aq) rd = max(rd, rounds[p2] + 1);
+      }
+      rounds[q] = (uint8_t)rd;
+      max_round = max(max_round, rd);
+    }
+    l.flags[0] = max_round;
+    l.flags[2] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int max_round = l.flags[0];
+  for (int rd = 0; rd <= max_round; rd++) {
+    for (int q0 = 0; q0 < count; q0 += MG_FUSED_SLOTS) {
+      const int q = q0 + lane;
+      if (lane < MG_FUSED_SLOTS && q < count && rounds[q] == rd) {
+        const uint8_t* rec = recs + q * 32;
+        const int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
+        const int act = *(const int*)(rec + 4);
+        cx.tmp = l.tmp + lane * 96;
+        int* near = cx.tmp;
+        uint8_t* vibes = (uint8_t*)(cx.tmp + 8);
+        for (int i = 0; i < 8; i++) {
+          near[i] = rec[8 + i];
+          vibes[i] = rec[16 + i];
+        }
+        const bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
+        if (ok) {
+          l.ag[actor].succ[MG_ACT_MOVE] += 1;
+          l.exec[actor] = act;
+          l.succ[actor] = 1;
+        } else {
+          l.ag[actor].fail[MG_ACT_MOVE] += 1;
+        }
+        if (cx.asm_dirty) l.flags[2] = 1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// Integer sums of the tokens_* deltas over the agents; exact f32 result when nothing passes 2^24, else the reference's
+// sequential f32 adds in agent order (mettagrid_c.cpp:552-554).  Thread 0 of the workgroup applies them.
+__device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& l) {
+  int sw = 0, sd = 0, sf = 0;
+  for (int i = 0; i < a.A; i++) {
+    const int att = l.tok_att[i];
+    const int wr = att < a.T ? att : a.T;
+    sw += wr;
+    sd += att - wr;
+    sf += a.T - wr;
+  }
+  const float w0 = l.tokacc[0], d0 = l.tokacc[1], f0 = l.tokacc[2];
+  const float lim = 16777216.0f;  // below 2^24 every partial sum is an integer f32 represents exactly
+  if (w0 + (float)sw < lim && d0 + (float)sd < lim && f0 + (float)sf < lim && sw < (1 << 23) && sd < (1 << 23) && sf < (1 << 23)) {
+    l.tokacc[0] = w0 + (float)sw;
+    l.tokacc[1] = d0 + (float)sd;
+    l.tokacc[2] = f0 + (float)sf;
+  } else {
+    mg_token_stats(a, l, 1);
+  }
+}
+
+// Fresh copies of the kernel arguments and the LDS carve for one phase, derived from an opaque kernarg pointer: the
+// values of the previous phase cannot be kept alive across the phase boundary (they would be spilled there: the phases
+// together need several times the registers any one of them does).
+template <bool DCL>
+__device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __attribute__((address_space(4))) KArgs* ka =
+      (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  a = *ka;
+#endif
+  mg_carve_fused<true>(smem, &l, a.A, a.SG, a.ROWB, MG_FUSED_THREADS >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
+                       a.NWINCELLS);
+  const int e = blockIdx.x + a.env_base;
+  l.gmap = a.map_cells8 + (size_t)map_id * a.HW8;
+  l.as = a.asms + (size_t)e * a.NAmax;                             // used in place (HBM)
+  l.ainfo = (int4*)(a.map_asm + (size_t)map_id * a.NAmax);         // read only
+  if (DCL) a.dc = l.dc;
+  a.H = H;
+  a.W = W;
+}
+
+template <bool DCL>
+__global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArgs a0) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, nt = MG_FUSED_THREADS;
+  const int lane = tid & 63, wave = tid >> 6;
+  DEnv env;
+  int H, W, act = 0, NW_, actor = 0;
+  uint32_t mt_raw = 0;
+
+  // ---- P0: stage -----------------------------------------------------------------------------------------------
+  {
+    KArgs a = a0;
+    const int e = blockIdx.x + a.env_base;
+    Lds l;
+    const int NP = a.NWINCELLS;
+    mg_carve_fused<true>(smem, &l, a.A, a.SG, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP, NP);
+    MG_STAMP(0);
+    // Everything that depends on nothing but e is requested before the env words are waited for.  A restart rewrites
+    // the records, so that rare case loads them again.
+    const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
+    const int n1 = a.A * (int)(sizeof(DAgent) / 16);
+    const bool two_pass = n1 <= 2 * nt;  // the usual shapes: at most two record chunks per thread
+    uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1;
+    if (two_pass) {
+      if (tid < n1) v1 = s1[tid];
+      if (tid + nt < n1) v2 = s1[tid + nt];
+    }
+    if (DCL) {
+      const uint4* __restrict__ s0 = (const uint4*)a.gdc;
+      uint4* d0 = (uint4*)l.dc;
+      for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
+    }
+    env = a.env[e];
+    const bool do_reset = a.auto_reset && env.done;  // block-uniform
+    if (do_reset) mg_restart_env(a, e, env, tid, nt);
+    mg_use_map(a, env.map_id);
+    H = a.H;
+    W = a.W;
+    NW_ = a.NWIN < 64 ? a.NWIN : 64;
+    const uint32_t* mt = a.mt + (size_t)e * 624;
+    const bool need_twist = (int)env.mt_idx + NW_ > 624;  // block-uniform
+    {  // (every wave: cheaper than choosing the acting wave before the loads)
+      if (lane < a.A) act = a.actions[(size_t)e * a.A + lane];
+      const int j = (int)env.mt_idx + lane;
+      if (lane < NW_ && j < 624) mt_raw = mt[j];
+    }
+    if (two_pass && !do_reset) {
+      if (tid < n1) ((uint4*)l.ag)[tid] = v1;
+      if (tid + nt < n1) ((uint4*)l.ag)[tid + nt] = v2;
+    } else {
+      for (int i = tid; i < n1; i += nt) ((uint4*)l.ag)[i] = s1[i];
+    }
+    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+    for (int i = tid; i < a.A; i += nt) {
+      l.dirty_amt[i] = 0;
+      l.dirty_misc[i] = 0;
+    }
+    for (int i = tid; i < ((nt >> 6) * 2 * l.WS) >> 2; i += nt) ((uint32_t*)l.wscr)[i] = 0;
+    {  // window cell -> position in the pattern order
+      const int hr = a.gdc[DC_OBS_H] >> 1, wr = a.gdc[DC_OBS_W] >> 1, ow = a.gdc[DC_OBS_W], op = a.gdc[DC_OFF_PATTERN];
+      for (int p = tid; p < NP; p += nt) {
+        const uint32_t packed = (uint32_t)a.gdc[op + p];
+        const int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
+        l.ipat[(dr + hr) * ow + dcc + wr] = (uint8_t)p;
+      }
+    }
+    if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+    if (tid == 0) {
+      l.flags[3] = 0;
+      l.flags[2] = 0;
+    }
+    if (need_twist) {  // next MT19937 block (rare: once per 624 outputs of an environment)
+      for (int i = tid; i < 227; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+      __syncthreads();
+      for (int i = 227 + tid; i < 454; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+      __syncthreads();
+      for (int i = 454 + tid; i < 623; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+      __syncthreads();
+      if (tid == 0) l.mtnext[623] = mt_mix(mt[623], l.mtnext[0], l.mtnext[396]);
+    }
+    env.step += 1;
+    actor = (a.diag & 4096) ? 0 : (int)(blockIdx.x & 1u);  // spread the single-wave phases over the SIMDs
+    __syncthreads();
+    MG_STAMP(1);
+  }
+
+  // ---- P1: actions (one wave) ------------------------------------------------------------------------------------
+  if (wave == actor) {
+    KArgs a;
+    Lds l;
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    const int e = blockIdx.x + a.env_base;
+    uint32_t w = 0;
+    {
+      const int j = (int)env.mt_idx + lane;
+      if (lane < NW_) w = mt_temper(j < 624 ? mt_raw : l.mtnext[j - 624]);
+    }
+    int n_pending = 0;
+    const uint32_t used = mg_fused_act(a, l, env, lane, act, w, NW_, &n_pending);
+    uint32_t new_idx = env.mt_idx + used;
+    if (new_idx > 624) {  // == 624: the block is exhausted but untwisted; the next step twists it
+      uint32_t* mtw = a.mt + (size_t)e * 624;
+      for (int i = lane; i < 624; i += 64) mtw[i] = l.mtnext[i];
+      new_idx -= 624;
+    }
+    env.mt_idx = new_idx;
+    if (lane == 0) {
+      a.env[e] = env;  // (done / early_reset are updated by the closing phase)
+      l.flags[3] = n_pending;
+      if (env.error) atomicOr(&a.status[0], env.error);
+    }
+  }
+  __syncthreads();
+
+  // ---- P2: assembler uses (one wave) -----------------------------------------------------------------------------------
+  {
+    KArgs a;
+    Lds l;
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    const int e = blockIdx.x + a.env_base;
+    MG_STAMP(2);
+    const int n_uses = l.flags[3];
+    if (n_uses > 0) {  // block-uniform
+      Ctx cx;
+      mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
+      cx.grid = nullptr;
+      if (wave == actor) mg_fused_uses(a, l, cx, n_uses, lane);
+      __syncthreads();
+      mg_flush_stats(a, l, cx, e, tid, nt);
+    }
+    MG_STAMP(3);
+  }
+
+  // ---- P3: observations, rewards, flags -----------------------------------------------------------------------------
+  {
+    KArgs a;
+    Lds l;
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    __syncthreads();  // (the use scratch becomes the token lists)
+    mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
+    __syncthreads();
+    MG_STAMP(4);
+  }
+  {
+    KArgs a;
+    Lds l;
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    const int e = blockIdx.x + a.env_base;
+    if (!(a.diag & 16)) mg_encode_all<uint8_t, false, true>(a, l, e, env.step, l.exec, true, tid, nt);
+    __syncthreads();
+    MG_STAMP(5);
+  }
+  {
+    KArgs b;
+    Lds l;
+    mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id);
+    const int e = blockIdx.x + b.env_base;
+    if (tid == 0) {
+      mg_fused_token_stats(b, l);
+      float* gs_ = b.gstats + (size_t)e * b.SG;
+      gs_[0] = l.tokacc[0];
+      gs_[1] = l.tokacc[1];
+      gs_[2] = l.tokacc[2];
+    }
+    __syncthreads();
+    mg_rewards_and_flags<true>(b, l, e, env, tid, nt);
+    __syncthreads();
+    uint4* wd = (uint4*)(b.agents + (size_t)e * b.A);
+    const uint4* ws = (const uint4*)l.ag;
+    for (int i = tid; i < b.A * (int)(sizeof(DAgent) / 16); i += nt) wd[i] = ws[i];
+    if (b.dbg && tid == 0) b.dbg[(size_t)e * 16 + 6] = clock64();
+  }
+}
+
+void mg_launch_fused(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st) {
+  if (dcl) hipLaunchKernelGGL(mg_step_fused_kernel<true>, dim3(n), dim3(MG_FUSED_THREADS), lds, st, k);
+  else hipLaunchKernelGGL(mg_step_fused_kernel<false>, dim3(n), dim3(MG_FUSED_THREADS), lds, st, k);
+}
+size_t mg_fused_lds_bytes(const KArgs& k, bool dcl) {
+  return mg_carve_fused<false>(nullptr, nullptr, k.A, k.SG, k.ROWB, MG_FUSED_THREADS / 64, dcl ? k.dc_obs_words : 0, k.NOBJ,
+                               k.HEAP, k.NWINCELLS);
+}
+hipError_t mg_raise_lds_cap_fused(int cap) {
+  hipError_t e = hipFuncSetAttribute((const void*)mg_step_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)mg_step_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+}

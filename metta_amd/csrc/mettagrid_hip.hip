@@ -122,8 +122,11 @@ struct mg_handle {
   KArgs k;
   std::vector<void*> allocs;
   std::vector<void*> map_allocs;
-  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0;
+  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0, lds_fused = 0;
   bool dc_lds = false;
+  bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
+  bool fused_dcl = false, cells8 = false;
+  bool no_modifiers = false;       // no group / chest has inventory-limit modifiers: the leaner build of the fused kernel
   bool big = false;                // map tile too large for LDS: grid (and, for obs/reset, agent records) in HBM
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -250,6 +253,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &d_dc, dcfg.size())) return 1;
   HIPCHK(hipMemcpy(d_dc, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice));
   k.dc = d_dc;
+  k.gdc = d_dc;
   k.dc_words = (int)dcfg.size();
   k.dc_obs_words = dcfg[DC_OBS_WORDS];
   size_t N = (size_t)num_envs * c.A;
@@ -422,6 +426,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   const int NOBJ = (int)c.walls.size() + c.A + NAmax + NCmax;
   const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS + NCmax * TSC;
   const int NP = c.obs_h * c.obs_w;
+  k.NWINCELLS = NP;
   k.NW = (int)c.walls.size(); k.NOBJ = NOBJ; k.TSW = TSW; k.TSA = TSA; k.TSS = TSS; k.TSC = TSC; k.NCmax = NCmax; k.HEAP = HEAP;
   {
     int mx = std::max(TSW, std::max(TSA, TSS));
@@ -491,9 +496,44 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
                 ", obs " + std::to_string(h->lds_obs) + " bytes)");
   h->lds_uses = mg_carve_uses<false>(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
+  // Fused step (fast configs whose environment fits LDS): one launch per step.  The byte copy of the pool halves the
+  // tile where every object code fits a byte.
+  h->fused = false;
+  k.map_cells8 = nullptr;
+  k.HW8 = (int)mg_align16((size_t)HWp);
+  {
+    const char* nf = getenv("MG_NO_FUSED");
+    if (k.fast && !big && !(nf && nf[0] == '1')) {
+      h->cells8 = NOBJ <= 255;  // the kernel reads the static layer from the byte copy of the pool
+      h->fused_dcl = k.dc_obs_words <= MG_DC_LDS_MAX_WORDS;
+      h->lds_fused = mg_fused_lds_bytes(k, h->fused_dcl);
+      if (h->lds_fused > LDS_MAX / 2 && h->fused_dcl) {  // keep at least two workgroups per CU: drop the config copy first
+        h->fused_dcl = false;
+        h->lds_fused = mg_fused_lds_bytes(k, false);
+      }
+      h->fused = h->cells8 && h->lds_fused <= LDS_MAX;
+      if (h->fused) {
+        std::vector<uint8_t> c8((size_t)num_maps * k.HW8, 0);
+        for (int m = 0; m < num_maps; m++)
+          for (int i = 0; i < heights[m] * widths[m]; i++) c8[(size_t)m * k.HW8 + i] = (uint8_t)cells[(size_t)m * HWp + i];
+        uint8_t* d8 = nullptr;
+        if (dalloc(h, &d8, c8.size(), true)) return 1;
+        HIPCHK(hipMemcpy(d8, c8.data(), c8.size(), hipMemcpyHostToDevice));
+        k.map_cells8 = d8;
+      }
+      if (h->fused) {
+        h->no_modifiers = true;
+        for (const auto& g : c.groups)
+          for (const auto& lim : g.inv.limits) h->no_modifiers = h->no_modifiers && lim.modifiers.empty();
+        HIPCHK(mg_raise_lds_cap_fused((int)LDS_MAX));
+        HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
+      }
+    }
+  }
   if (getenv("MG_VERBOSE"))
-    fprintf(stderr, "mettagrid_hip: LDS bytes per workgroup: act %zu, obs %zu, uses %zu (dc words %d, obs prefix %d, heap %d tokens, %d objects)\n",
-            h->lds_act, h->lds_obs, h->lds_uses, k.dc_words, k.dc_obs_words, HEAP, NOBJ);
+    fprintf(stderr, "mettagrid_hip: LDS bytes per workgroup: act %zu, obs %zu, uses %zu, fused %zu%s (dc words %d, obs prefix %d, heap %d tokens, %d objects)\n",
+            h->lds_act, h->lds_obs, h->lds_uses, h->lds_fused, h->fused ? (h->cells8 ? " [byte tile]" : " [u16 tile]") : " [off]",
+            k.dc_words, k.dc_obs_words, HEAP, NOBJ);
   {
     // the cap on dynamic LDS is a per-function setting shared by every handle of the process: raise it once
     const int cap = (int)LDS_MAX;
@@ -661,14 +701,20 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
     KArgs kg = k;
     kg.env_base = (int)((long long)h->E * gi / G);
     const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
-    if (k.fast) {
-      mg_launch_act_fast(kg, n, st);
-      mg_launch_uses(kg, n, h->lds_uses, h->dc_lds, st);
+    if (h->fused) {
+      if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
+      if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
+      else mg_launch_fused(kg, n, h->lds_fused, h->fused_dcl, st);
     } else {
-      mg_launch_act(kg, n, h->lds_act, h->dc_lds, h->big, st);
+      if (k.fast) {
+        mg_launch_act_fast(kg, n, st);
+        mg_launch_uses(kg, n, h->lds_uses, h->dc_lds, st);
+      } else {
+        mg_launch_act(kg, n, h->lds_act, h->dc_lds, h->big, st);
+      }
+      if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
+      mg_launch_obs(kg, n, h->lds_obs, h->dc_lds, h->big, st);
     }
-    if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
-    mg_launch_obs(kg, n, h->lds_obs, h->dc_lds, h->big, st);
     if (gi > 0) {
       (void)hipEventRecord(h->ev_join[gi - 1], st);
       (void)hipStreamWaitEvent(s, h->ev_join[gi - 1], 0);

@@ -15,7 +15,7 @@ enum MgDc {
   DC_G_COMPLETION, DC_G_LAST_ACTION, DC_G_LAST_REWARD, DC_G_COMPASS, DC_G_GOAL, DC_PROTO_OBS,
   DC_REGEN_INTERVAL, DC_INIT_PASSES, DC_N_VIBES, DC_NG, DC_N_INV_TOKENS, DC_N_ACTIONS, DC_MAX_PRIORITY,
   DC_ATK_FREEZE, DC_SA, DC_SG, DC_PATTERN_N, DC_N_GROUPS, DC_N_WALLS, DC_N_ASMS, DC_N_CELLS, DC_HAS_DEFENSE, DC_HAS_DAMAGE, DC_N_CHESTS,
-  DC_OBS_WORDS,  // the stream's prefix that the observation kernel needs (action/attack/transfer tables come after it)
+  DC_OBS_WORDS,  // the stream's prefix that is staged in LDS for the observation / use code (pattern, action, attack and transfer tables come after it)
   DC_FID0,
   DC_OFF_FID_INV = DC_FID0 + MG_F_COUNT, DC_OFF_FID_IN, DC_OFF_FID_OUT, DC_OFF_ACTIONS,
   DC_OFF_HANDLERS,  // 6 offsets: required/consumed kv-lists of noop, move, change_vibe
@@ -245,6 +245,10 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
     for (size_t i = 0; i < table.size(); i++) b.w[(size_t)o + i] = table[i];
     H(DC_OFF_ASMS) = o;
   }
+  H(DC_OBS_WORDS) = (int32_t)((b.w.size() + 3) & ~(size_t)3);
+  while (b.w.size() % 4) b.w.push_back(0);
+  // ---- tables read through the global pointer only (KArgs::gdc): the observation pattern (once per wave), the cell
+  // table (host), and what only the action phase reads ----
   {
     std::vector<int32_t> pat = mg_pattern(c.obs_h, c.obs_w);
     H(DC_PATTERN_N) = (int32_t)pat.size();
@@ -260,9 +264,6 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
     }
     H(DC_OFF_CELLS) = o;
   }
-  H(DC_OBS_WORDS) = (int32_t)((b.w.size() + 3) & ~(size_t)3);
-  while (b.w.size() % 4) b.w.push_back(0);
-  // ---- tables only the action kernels read ----
   {
     int o = b.reserve((int)c.actions.size() * 2);
     for (size_t i = 0; i < c.actions.size(); i++) {

@@ -23,9 +23,12 @@
 
 struct KArgs {
   const int* dc;
+  const int* gdc;    // the whole config stream in HBM (dc may be re-pointed at an LDS copy of its prefix)
   int dc_obs_words;  // prefix of the stream the observation kernel stages
   int dc_words;  // size of the device config stream; staged in LDS when it fits (MG_DC_LDS_MAX_WORDS)
   const uint16_t* map_cells;  // [P][HW]
+  const uint8_t* map_cells8;  // [P][HW8] the same codes as bytes when every object code fits one (fused kernel), else null
+  int HW8;                    // byte stride of one map in map_cells8 (multiple of 16)
   const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
   const int* map_nasm;        // [P]
@@ -39,6 +42,7 @@ struct KArgs {
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
   int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
   int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
+  int NWINCELLS;           // cells of the observation window (obs_h * obs_w)
   int CB;                  // bits needed for the largest per-object token count
   int TSW, TSA, TSS, HEAP; // token-list strides of walls / agents / assemblers; heap size in tokens
   DEnv* env;
@@ -111,6 +115,12 @@ struct Lds {
   uint16_t* heap;   // token lists (feature | value << 8): [NW][TSW] walls, [A][TSA] agents, [NA][TSS] assemblers
   int4* ainfo;      // [NA] static assembler info of the map (r, c, cfg, object id)
   uint32_t* pat;    // [P] (dr+8) | (dc+8) << 8 | location byte << 16
+  uint8_t* pend;    // fused kernel: [A][32] assembler uses found by the action phase
+  uint8_t* succ;    // fused kernel: [A] action_success of this step
+  uint8_t* wscr;    // fused kernel: [waves][2][WS] agents inside the window being encoded (agent index + 1 per window cell)
+  uint8_t* ipat;    // fused kernel: [obs_h * obs_w] window cell -> position in the pattern order
+  const uint8_t* gmap;  // fused kernel: the byte map of this environment in the HBM pool (static layer)
+  int WS;
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -231,9 +241,12 @@ __device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, in
   }
 }
 
+// CT = cell type of the LDS grid tile: uint16_t, or uint8_t where every object code fits a byte (fused kernel)
+template <class CT = uint16_t>
 __device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
   const CellCodec cc{a.NW, a.A, a.NAmax};
-  for (int i = tid; i < a.A; i += nt) l.grid[(int)l.ag[i].r * a.W + l.ag[i].c] = cc.agent(i);
+  CT* grid = (CT*)l.grid;
+  for (int i = tid; i < a.A; i += nt) grid[(int)l.ag[i].r * a.W + l.ag[i].c] = (CT)cc.agent(i);
 }
 
 __device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
@@ -245,8 +258,19 @@ __device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
                                   : a.NW * a.TSW + a.A * a.TSA + a.NAmax * a.TSS + (obj - a.NW - a.A - a.NAmax) * a.TSC));
 }
 
+// Pattern entry p: (dr+8) | (dc+8) << 8 | location byte << 16
+// (`gdc` = the stream in HBM: the pattern lies behind the LDS-staged prefix)
+__device__ __forceinline__ uint32_t mg_pattern_entry(const int* gdc, int p) {
+  const int* dc = gdc;
+  const int hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
+  const uint32_t packed = (uint32_t)dc[dc[DC_OFF_PATTERN] + p];
+  const int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
+  return packed | ((uint32_t)(((dr + hr) << 4) | ((dcc + wr) & 0x0F)) << 16);
+}
+
 // Build every object's token list once (they are observer independent) and the pattern table.
 // Requires l.ainfo (the map's static assembler info) staged + a barrier before.
+template <class CT = uint16_t, bool PAT = true>
 __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
   const int* dc = a.dc;
   const CellCodec cc{a.NW, a.A, a.NAmax};
@@ -259,15 +283,13 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
     const int ho = mg_heap_off(a, obj);
     PairOut out{l.heap + ho, 0};
     if (obj < a.NW + a.A + nasm || (obj >= first_chest && obj < first_chest + nchest))
-      mg_object_tokens(dc, l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
+      mg_object_tokens(dc, (const CT*)l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
     l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
   }
   if (tid == 0) l.ocnt[-1] = 0;  // cell code 0 (empty) looks up "no tokens" without a branch
-  const int P = dc[DC_PATTERN_N], op = dc[DC_OFF_PATTERN], hr = dc[DC_OBS_H] >> 1, wr = dc[DC_OBS_W] >> 1;
-  for (int p = tid; p < P; p += nt) {
-    uint32_t packed = (uint32_t)dc[op + p];
-    int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
-    l.pat[p] = packed | ((uint32_t)(((dr + hr) << 4) | ((dcc + wr) & 0x0F)) << 16);
+  if (PAT) {
+    const int P = dc[DC_PATTERN_N];
+    for (int p = tid; p < P; p += nt) l.pat[p] = mg_pattern_entry(a.gdc, p);
   }
 }
 
@@ -327,7 +349,7 @@ __device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lan
 // Window lookups of one agent, all rounds (independent LDS reads: they overlap, and the caller issues them for both
 // agents of a pair before either row is written).  Window offsets never exceed the radius, so "inside the window and
 // the map" is just "inside the map".  meta = heap offset | token count << 16 per window cell.
-template <int NR, bool HOT>
+template <int NR, bool HOT, class CT = uint16_t>
 __device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
                                                  const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
                                                  uint32_t& rc) {
@@ -340,8 +362,53 @@ __device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, c
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
     const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && (HOT || !(a.diag & 512));
     // no branches: cells outside the map read cell 0 and are masked; empty cells read the zero entry ocnt[-1]
-    const uint32_t cv = l.grid[ok ? __mul24(r, W) + c : 0];
+    const uint32_t cv = ((const CT*)l.grid)[ok ? __mul24(r, W) + c : 0];
     meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];
+  }
+}
+
+// The same lookups without an occupancy tile in LDS (fused kernel): the static layer comes from the byte map of the
+// pool in HBM (L2-resident: every environment playing the map reads the same few KB), and the agents of the environment
+// that stand inside the window are scattered over the window cells through a small per-wave LDS buffer `ws` (all zero
+// between uses).  `posj` = position of agent `lane` (r | c << 16), loaded once per wave.
+template <int NR>
+__device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
+                                                        const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
+                                                        uint32_t& rc, const uint32_t posj, uint8_t* ws) {
+  const int H = ec.H, W = ec.W, P = ec.P;
+  rc = *(const uint32_t*)me;
+  const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
+  uint32_t cvs[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int p = q * 64 + lane;
+    const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
+    const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W;
+    const uint32_t v = l.gmap[ok ? __mul24(r, W) + c : 0];
+    cvs[q] = ok ? v : 0u;
+  }
+  const int jr = (int)(posj & 0xFFFF) - ar, jc = (int)(posj >> 16) - ac;
+  const bool inwin = lane < a.A && jr >= -ec.hr && jr <= ec.hr && jc >= -ec.wr && jc <= ec.wr;
+  int pj = 0;
+  if (inwin) {
+    pj = l.ipat[(jr + ec.hr) * ec.ow + jc + ec.wr];
+    ws[pj] = (uint8_t)(lane + 1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t aj[NR];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int p = q * 64 + lane;
+    aj[q] = p < l.WS ? ws[p] : 0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (inwin) ws[pj] = 0;
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const uint32_t cv = aj[q] ? (uint32_t)a.NW + aj[q] : cvs[q];  // agents stand on empty cells of the static layer
+    meta[q] = l.ocnt[(int)cv - 1];
   }
 }
 
@@ -431,7 +498,7 @@ __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, con
 
 // All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
 // Requires mg_build_tokens + a barrier before.
-template <int NR, bool PAIRS>
+template <int NR, bool PAIRS, class CT = uint16_t, bool PAT = true, bool DIRECT = false>
 __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                        bool write_global, int tid, int nt) {
   // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
@@ -443,7 +510,8 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   const GlobalTok gt = mg_global_tok(a, step, lane);
   uint32_t pk[MG_MAX_ROUNDS];
 #pragma unroll
-  for (int q = 0; q < MG_MAX_ROUNDS; q++) pk[q] = (q < NR && (q * 64 + lane) < ec.P) ? l.pat[q * 64 + lane] : 0u;
+  for (int q = 0; q < MG_MAX_ROUNDS; q++)
+    pk[q] = (q < NR && (q * 64 + lane) < ec.P) ? (PAT ? l.pat[q * 64 + lane] : mg_pattern_entry(a.gdc, q * 64 + lane)) : 0u;
   // Rows whose length is 8 mod 16 (T = 200: 600 bytes) alternate between phase 0 and 8 in HBM.  A wave then takes
   // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
   // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
@@ -454,6 +522,8 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   constexpr int group = pairs ? 2 : 1;
   const int nfill = a.ROWB >> 4;
   uint2 carry = make_uint2(0, 0);
+  uint32_t posj = 0;
+  if (DIRECT && lane < a.A) posj = *(const uint32_t*)&l.ag[lane];
   // per-agent offsets are carried along instead of multiplied out (v_mul_lo_u32 runs at quarter rate)
   uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
   const DAgent* me0 = l.ag + wave * group;
@@ -462,7 +532,12 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   {
     uint32_t meta[group][NR], rc[group];
 #pragma unroll
-    for (int h = 0; h < group; h++) mg_window_lookup<NR, PAIRS>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
+    for (int h = 0; h < group; h++) {
+      if (DIRECT)
+        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS);
+      else
+        mg_window_lookup<NR, PAIRS, CT>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
+    }
 #pragma unroll
     for (int h = 0; h < group; h++) {
       const int ai = a0 + h;
@@ -522,11 +597,12 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
 
 // The headline shape (window of at most 128 cells, rows of 8 mod 16 bytes in pairs: 11 x 11 window, 200 tokens) has
 // a loop of its own, so that the general loop's state stays out of its registers.
+template <class CT = uint16_t, bool PAT = true, bool DIRECT = false>
 __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                      bool write_global, int tid, int nt) {
   const bool pairs = write_global && (a.A & 1) == 0 && ((a.T * 3) & 15) == 8 && a.ROWB <= 1024;
-  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true>(a, l, e, step, exec, write_global, tid, nt);
-  else mg_encode_all_t<MG_MAX_ROUNDS, false>(a, l, e, step, exec, write_global, tid, nt);  // any shape
+  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true, CT, PAT, DIRECT>(a, l, e, step, exec, write_global, tid, nt);
+  else mg_encode_all_t<MG_MAX_ROUNDS, false, CT, PAT, DIRECT>(a, l, e, step, exec, write_global, tid, nt);  // any shape
 }
 
 // Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
@@ -687,6 +763,9 @@ __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& c
 }
 
 // Agent::compute_stat_rewards (agent.cpp:103-132) + episode bookkeeping (bindings/mettagrid_c.cpp:656-677).
+// FUSED: the records are written back whole afterwards (no separate store of cur_reward), and stat slots that other
+// threads of this launch added to with atomics are read past the L1 (agent-scope loads).
+template <bool FUSED = false>
 __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e, DEnv env, int tid, int nt) {
   const int* dc = a.dc;
   const MgAgentSlots AS{a.R, a.NG};
@@ -727,9 +806,12 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
           else if (aslot == AS.failed_any())
             v = (float)(me->fail[0] + me->fail[1] + me->fail[2]);
           else
-            v = as_[ai * a.SA + aslot];
+            v = FUSED ? __hip_atomic_load(&as_[ai * a.SA + aslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : as_[ai * a.SA + aslot];
         }
-        if (gslot >= 0) v += gslot < 3 ? l.tokacc[gslot] : gs_[gslot];
+        if (gslot >= 0)
+          v += gslot < 3 ? l.tokacc[gslot]
+                         : (FUSED ? __hip_atomic_load(&gs_[gslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs_[gslot]);
         float rew = v * __int_as_float(sr[2]);
         if (sr[3]) {
           float mx = __int_as_float(sr[4]);
@@ -741,11 +823,12 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
       if (delta != 0.0f) {
         reward = delta;
         me->cur_reward = total;
-        a.agents[g].cur_reward = total;
+        if (!FUSED) a.agents[g].cur_reward = total;
       }
     }
     a.rewards[g] = reward;
     a.ep_rewards[g] += reward;
+    if (FUSED) a.success[g] = l.succ[ai];
     if (end_now) {
       if (trunc_now) a.trunc[g] = 1; else a.term[g] = 1;
     }
@@ -914,6 +997,12 @@ void mg_launch_uses(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_
 void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_act.hip
 void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_obs.hip
 void mg_launch_reset(const KArgs& k, unsigned n, size_t lds, bool big, hipStream_t st);               // k_reset.hip
+// k_fused.hip: the whole step of one environment in one workgroup (attack-free configs, A <= 64)
+void mg_launch_fused(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);
+size_t mg_fused_lds_bytes(const KArgs& k, bool dcl);
+hipError_t mg_raise_lds_cap_fused(int cap);
+void mg_launch_fused_nomod(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_nomod.hip
+hipError_t mg_raise_lds_cap_fused_nomod(int cap);
 // the cap on dynamic LDS is a per-function setting shared by every handle of the process
 hipError_t mg_raise_lds_cap_uses(int cap);
 hipError_t mg_raise_lds_cap_act(int cap);

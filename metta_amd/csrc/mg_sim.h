@@ -179,7 +179,12 @@ __device__ inline void mg_map_erase(DAgent* a, int k) {
 __device__ inline int mg_effective_limit(const int* dc, const int* gr, const DAgent* a, int li) {
   int base = dc[gr[GR_OFF_LIMITS] + 2 * li] & 0xFFFF;
   int eff = base;
-  if (gr[GR_HAS_MODIFIERS]) {
+#ifndef MG_NO_MODIFIERS
+  if (gr[GR_HAS_MODIFIERS])
+#else
+  if (false)
+#endif
+  {
     int mo = dc[gr[GR_OFF_LIMITS] + 2 * li + 1];
     int n = L_n(dc, mo);
     for (int i = 0; i < n; i++) eff += (int)a->amt[KV_k(dc, mo, i)] * (KV_v(dc, mo, i) & 0xFFFF);
@@ -236,8 +241,13 @@ template <int D>
 __device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, bool ignore_limits);
 
 // Inventory::enforce_all_limits (inventory.cpp:126-158); nesting bounded at depth 3.
+// A translation unit built with MG_NO_MODIFIERS serves configurations without limit modifiers only (host-checked): the
+// four nested copies of the update code below cost every caller their registers, and those configurations never get here.
 template <int D>
 __device__ void mg_enforce_limits(Ctx& cx, int ai) {
+#ifdef MG_NO_MODIFIERS
+  return;
+#endif
   DAgent* a = mg_holder(cx, ai);
   const int* dc = cx.dc;
   const int* gr = group_rec(dc, a->group);
@@ -283,7 +293,9 @@ __device__ int mg_inv_update(Ctx& cx, int ai, int item, int attempted_delta, boo
   if (clamped == 0) mg_map_erase(a, item);
   int cd = clamped - initial;
   if (cd != 0) mg_on_change(cx, ai, item, cd);
+#ifndef MG_NO_MODIFIERS
   if (cd < 0 && dc[gr[GR_OFF_MODIFIER] + item]) mg_enforce_limits<D>(cx, ai);
+#endif
   return cd;
 }
 __device__ inline int inv_update(Ctx& cx, int ai, int item, int delta, bool ignore = false) {
@@ -413,10 +425,21 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long l
 }
 
 // Assembler::get_current_protocol on the grid as it stands (assembler.hpp:353-408).
-__device__ inline int mg_current_protocol(const int* dc, const uint16_t* grid, const DAgent* ag, CellCodec codec, int H,
+template <class CT>
+__device__ inline int mg_current_protocol(const int* dc, const CT* grid, const DAgent* ag, CellCodec codec, int H,
                                           int W, int ar, int ac, int cfg, bool clipped) {
   unsigned long long vibes = 0;
   int n_agents = 0;
+  if (!grid) {  // no occupancy tile (fused kernel): the surrounding agents by position (any order: the key is sorted)
+    for (int j = 0; j < codec.A; j++) {
+      const int dr = (int)ag[j].r - ar, dcl = (int)ag[j].c - ac;
+      if (dr >= -1 && dr <= 1 && dcl >= -1 && dcl <= 1 && !(dr == 0 && dcl == 0)) {
+        if (n_agents < 8) vibes |= (unsigned long long)ag[j].vibe << (8 * n_agents);
+        n_agents++;
+      }
+    }
+    return mg_select_protocol(dc, cfg, vibes, n_agents, clipped);
+  }
   for (int i = -1; i <= 1; i++)
     for (int j = -1; j <= 1; j++) {
       if (i == 0 && j == 0) continue;
@@ -1000,8 +1023,8 @@ __device__ inline void mg_inventory_tokens(const int* dc, const DAgent* a, OUT& 
   }
 }
 
-template <class OUT>
-__device__ inline void mg_object_tokens(const int* dc, const uint16_t* grid, const DAgent* ag, const DAsm* as,
+template <class OUT, class CT>
+__device__ inline void mg_object_tokens(const int* dc, const CT* grid, const DAgent* ag, const DAsm* as,
                                         const int4* asm_info, CellCodec cc, int H, int W, uint32_t step, uint16_t cv,
                                         OUT& out, const DAgent* chests = nullptr, const int4* chest_info = nullptr) {
   int kind = cc.kind(cv);

@@ -132,8 +132,15 @@ class MettaGridDeviceVecEnv:
         self._status_dev = self.batch.status_tensor()
         self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
         self._status_event = None
+        self._status_age = 0
         self._finished_seen = 0
         self.host_syncs = 0  # blocking device->host reads issued by send() (tests assert on it)
+        # Only the latest finished episode of an environment is kept on the device, so the host may not fall a whole
+        # episode behind: when a queued status copy is older than this many steps, send() waits for THAT copy (the
+        # device still has the younger steps queued, so it does not idle).
+        ms = int(self.cfg.game.max_steps)
+        self.max_status_lag = max(1, min(32, ms // 2)) if ms > 0 else 32
+        self.backpressure_waits = 0
 
     # ---- buffers (pufferlib.set_buffers names, PUF/pufferlib.py:18-45) ------------------------------------
     @property
@@ -220,6 +227,11 @@ class MettaGridDeviceVecEnv:
         """Non-blocking: look at the last completed copy of the status word, then queue the next copy."""
         torch = self.batch._torch
         ev = self._status_event
+        if ev is not None:
+            self._status_age += 1
+            if self._status_age >= self.max_status_lag and not ev.query():
+                ev.synchronize()
+                self.backpressure_waits += 1
         if ev is not None and ev.query():
             err, finished = int(self._status_host[0]) & 0xFFFFFFFF, int(self._status_host[1]) & 0xFFFFFFFF
             self._status_event = None
@@ -233,6 +245,7 @@ class MettaGridDeviceVecEnv:
             self._status_host.copy_(self._status_dev, non_blocking=True)
             self._status_event = torch.cuda.Event()
             self._status_event.record(torch.cuda.current_stream(self.batch.device))
+            self._status_age = 0
 
     def flush_infos(self) -> list:
         """Synchronise and collect every finished episode not yet reported (end of a rollout / before closing)."""

@@ -14,10 +14,14 @@ native.check(b.L.mg_debug_stamps(b._h, None, 1))
 b.step(tab[0]); torch.cuda.synchronize()
 out=np.zeros((E,16),np.uint64)
 native.check(b.L.mg_debug_stamps(b._h, out.ctypes.data_as(ct.POINTER(ct.c_uint64)), 1))
+t0=int(out[:,0].min())
+print("start offsets (first/second wave of workgroups): median", np.median(out[:,0].astype(np.int64)-t0), "p90", np.percentile(out[:,0].astype(np.int64)-t0,90))
+print("uses/no-uses split of stage 2->3:", np.percentile(np.diff(out[:,2:4].astype(np.int64),axis=1),[10,50,90,99]))
 d=np.diff(out[:,:7].astype(np.int64),axis=1)
 print("phase medians (stamp units):", np.median(d,axis=0), "mean", d.mean(axis=0))
 print("total per block median", np.median(out[:,6].astype(np.int64)-out[:,0].astype(np.int64)))
 print("kernel span", int(out[:,6].max()-out[:,0].min()))
 m = out[:,8] != 0
-u = out[m][:, 8:12].astype(np.int64)
-print("uses envs", int(m.sum()), "of", E, " phases (stage, serial, flush) median:", np.median(np.diff(u,axis=1),axis=0), "max:", np.diff(u,axis=1).max(axis=0))
+if m.any():
+    u = out[m][:, 8:12].astype(np.int64)
+    print("uses envs", int(m.sum()), "of", E, " phases (stage, serial, flush) median:", np.median(np.diff(u,axis=1),axis=0), "max:", np.diff(u,axis=1).max(axis=0))
