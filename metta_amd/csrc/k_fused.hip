@@ -380,25 +380,38 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
   }
 }
 
-// Integer sums of the tokens_* deltas over the agents; exact f32 result when nothing passes 2^24, else the reference's
-// sequential f32 adds in agent order (mettagrid_c.cpp:552-554).  Thread 0 of the workgroup applies them.
-__device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& l) {
+// tokens_* game stats (mettagrid_c.cpp:552-554): the reference adds three f32 values per agent, in agent order.  While
+// every partial sum stays below 2^24 those adds are exact, so the sums may be formed as integers by one wave (DPP
+// reduction) and added once; beyond, thread 0 repeats the reference's sequential f32 adds.  First wave only.
+__device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& l, const int lane) {
   int sw = 0, sd = 0, sf = 0;
-  for (int i = 0; i < a.A; i++) {
+  for (int i = lane; i < a.A; i += 64) {
     const int att = l.tok_att[i];
     const int wr = att < a.T ? att : a.T;
     sw += wr;
     sd += att - wr;
     sf += a.T - wr;
   }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sw += __shfl_xor(sw, off);
+    sd += __shfl_xor(sd, off);
+    sf += __shfl_xor(sf, off);
+  }
   const float w0 = l.tokacc[0], d0 = l.tokacc[1], f0 = l.tokacc[2];
-  const float lim = 16777216.0f;  // below 2^24 every partial sum is an integer f32 represents exactly
-  if (w0 + (float)sw < lim && d0 + (float)sd < lim && f0 + (float)sf < lim && sw < (1 << 23) && sd < (1 << 23) && sf < (1 << 23)) {
-    l.tokacc[0] = w0 + (float)sw;
-    l.tokacc[1] = d0 + (float)sd;
-    l.tokacc[2] = f0 + (float)sf;
-  } else {
-    mg_token_stats(a, l, 1);
+  const float lim = 16777216.0f;
+  const bool exact = w0 + (float)sw < lim && d0 + (float)sd < lim && f0 + (float)sf < lim && sw < (1 << 23) &&
+                     sd < (1 << 23) && sf < (1 << 23);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    if (exact) {
+      l.tokacc[0] = w0 + (float)sw;
+      l.tokacc[1] = d0 + (float)sd;
+      l.tokacc[2] = f0 + (float)sf;
+    } else {
+      mg_token_stats(a, l, 1);
+    }
   }
 }
 
@@ -581,12 +594,14 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
     Lds l;
     mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id);
     const int e = blockIdx.x + b.env_base;
-    if (tid == 0) {
-      mg_fused_token_stats(b, l);
-      float* gs_ = b.gstats + (size_t)e * b.SG;
-      gs_[0] = l.tokacc[0];
-      gs_[1] = l.tokacc[1];
-      gs_[2] = l.tokacc[2];
+    if (wave == 0) {
+      mg_fused_token_stats(b, l, lane);
+      if (lane == 0) {
+        float* gs_ = b.gstats + (size_t)e * b.SG;
+        gs_[0] = l.tokacc[0];
+        gs_[1] = l.tokacc[1];
+        gs_[2] = l.tokacc[2];
+      }
     }
     __syncthreads();
     mg_rewards_and_flags<true>(b, l, e, env, tid, nt);

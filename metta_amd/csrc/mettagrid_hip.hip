@@ -56,6 +56,7 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   cx.H = a.H; cx.W = a.W; cx.A = 1; cx.NA = 0; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG; cx.step = 0;
   cx.asm_dirty = 0; cx.AS = MgAgentSlots{a.R, a.NG}; cx.GS = MgGameSlots{a.R, a.n_cells - 1}; cx.cc = CellCodec{a.NW, a.A, a.NAmax};
   cx.ch = nullptr; cx.chest_info = nullptr; cx.NC = 0; cx.gsetv = nullptr; cx.gsetm = nullptr; cx.overflow = 0;
+  cx.gset64 = nullptr; cx.seq = 0;
   float* as_ = cx.astats;
   uint32_t* at_ = cx.atouched;
   uint8_t existing[MGD_MAX_R];
@@ -485,14 +486,15 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   h->dc_lds = !big && k.dc_words <= MG_DC_LDS_MAX_WORDS;
   int dcw = h->dc_lds ? k.dc_words : 0;
   int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
-  h->lds_act = mg_carve<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, dcw, 0, 0, 0, -1, NCmax);
+  k.NAmax = NAmax; k.NCmax = NCmax; k.HW = HWp;
+  h->lds_act = mg_act_lds_bytes(k, dcw != 0, big);
   h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
-  if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX) {
+  if (h->lds_act > LDS_MAX - 1024 || h->lds_obs > LDS_MAX) {
     h->dc_lds = false;
-    h->lds_act = mg_carve<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.SA, k.SG, k.NWIN, k.ROWB, 0, 0, 0, 0, 0, -1, NCmax);
+    h->lds_act = mg_act_lds_bytes(k, false, big);
     h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   }
-  if (h->lds_act > LDS_MAX || h->lds_obs > LDS_MAX)
+  if (h->lds_act > LDS_MAX - 1024 || h->lds_obs > LDS_MAX)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +
                 ", obs " + std::to_string(h->lds_obs) + " bytes)");
   h->lds_uses = mg_carve_uses<false>(nullptr, nullptr, c.A, NAmax, k.SG, h->dc_lds ? k.dc_words : 0);
@@ -537,7 +539,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   {
     // the cap on dynamic LDS is a per-function setting shared by every handle of the process: raise it once
     const int cap = (int)LDS_MAX;
-    HIPCHK(mg_raise_lds_cap_act(cap));
+    HIPCHK(mg_raise_lds_cap_act(cap - 1024));  // (the kernel also holds a little static LDS: block-wide votes)
     HIPCHK(mg_raise_lds_cap_uses(cap));
     HIPCHK(mg_raise_lds_cap_obs(cap));
     HIPCHK(mg_raise_lds_cap_reset(cap));

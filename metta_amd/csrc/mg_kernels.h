@@ -99,6 +99,7 @@ struct Lds {
   DAgent* ch;       // chest records (directly after the agent records)
   int* gsetv;       // [16] pending chest.<r>.amount values; gsetm[0] = which
   uint32_t* gsetm;
+  unsigned long long* gset64;  // [16] the same as sequence-keyed maxima (parallel action rounds), or null
   DAsm* as;
   int* gd;
   uint32_t* dirty_amt;
@@ -163,7 +164,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
-    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64);
+    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64); l->gset64 = nullptr;
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
     l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);
@@ -755,10 +756,22 @@ __device__ inline void mg_flush_stats(const KArgs& a, const Lds& l, const Ctx& c
       atomicOr(&gt_[i >> 5], 1u << (i & 31));
     }
   }
-  if (a.NCmax > 0 && tid < a.R && ((*l.gsetm >> tid) & 1u)) {  // StatsTracker::set of chest.<r>.amount
-    const int s = cx.GS.chest_amount(tid);
-    gs_[s] = (float)l.gsetv[tid];
-    atomicOr(&gt_[s >> 5], 1u << (s & 31));
+  if (a.NCmax > 0 && tid < a.R) {  // StatsTracker::set of chest.<r>.amount
+    bool have = false;
+    int value = 0;
+    if (cx.gset64) {
+      const unsigned long long v = cx.gset64[tid];
+      have = v != 0ull;
+      value = (int)(v & 0xFFFFull);
+    } else if ((*l.gsetm >> tid) & 1u) {
+      have = true;
+      value = l.gsetv[tid];
+    }
+    if (have) {
+      const int s = cx.GS.chest_amount(tid);
+      gs_[s] = (float)value;
+      atomicOr(&gt_[s >> 5], 1u << (s & 31));
+    }
   }
 }
 
@@ -864,6 +877,8 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e,
   cx.NC = a.NCmax;
   cx.gsetv = l.gsetv;
   cx.gsetm = l.gsetm;
+  cx.gset64 = nullptr;
+  cx.seq = 0;
   cx.overflow = 0;
 }
 
@@ -991,10 +1006,11 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
 // ---- launchers (one per kernel translation unit) ---------------------------------------------------------------
 #define MG_FAST_THREADS 64
 #define MG_USES_THREADS 64
-#define MG_ACT_THREADS 64
 void mg_launch_act_fast(const KArgs& k, unsigned n, hipStream_t st);                                   // k_act_fast.hip
 void mg_launch_uses(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);                // k_uses.hip
 void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_act.hip
+size_t mg_act_lds_bytes(const KArgs& k, bool dcl, bool big);
+int mg_act_threads(const KArgs& k);
 void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_obs.hip
 void mg_launch_reset(const KArgs& k, unsigned n, size_t lds, bool big, hipStream_t st);               // k_reset.hip
 // k_fused.hip: the whole step of one environment in one workgroup (attack-free configs, A <= 64)

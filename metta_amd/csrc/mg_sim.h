@@ -86,6 +86,11 @@ struct Ctx {
   int NC;
   int* gsetv;                         // [R] pending StatsTracker::set of chest.<r>.amount (last writer wins) ...
   uint32_t* gsetm;                    // ... and which of them are pending
+  // Parallel action rounds (k_act.hip): "last writer" means last in the reference's action order, not in time.  Each set
+  // carries a sequence key (the acting agent's rank, then a per-action counter); the largest key wins (atomic max of
+  // key << 16 | amount).  Null = the single-writer form above.
+  unsigned long long* gset64;
+  uint32_t seq;
   int H, W, A, NA, R, SA, SG, NG;
   uint32_t step;
   int asm_dirty;
@@ -216,8 +221,13 @@ __device__ inline void mg_on_change(Ctx& cx, int ai, int item, int delta) {
       atomicAdd(&cx.gd[cx.GS.chest_deposited(item)], delta);
     else if (delta < 0)
       atomicAdd(&cx.gd[cx.GS.chest_withdrawn(item)], -delta);
-    cx.gsetv[item] = (int)cx.ch[ai - cx.A].amt[item];
-    *cx.gsetm |= 1u << item;
+    if (cx.gset64) {
+      const unsigned long long key = cx.seq++;
+      atomicMax(&cx.gset64[item], (key << 16) | (unsigned long long)cx.ch[ai - cx.A].amt[item]);
+    } else {
+      cx.gsetv[item] = (int)cx.ch[ai - cx.A].amt[item];
+      *cx.gsetm |= 1u << item;
+    }
     return;
   }
   DAgent* a = &cx.ag[ai];
@@ -931,26 +941,36 @@ __device__ inline void mg_shuffle(uint16_t* v, int n, RngWin& g) {
 // Agent::check_and_apply_damage (agent.cpp:134-177): when every threshold resource is held, pay the thresholds and
 // lose one unit of a resource drawn by std::discrete_distribution over the amounts above the protected minimum
 // (random.tcc:2656-2713: cumulative probabilities in double, last forced to 1, lower_bound of a canonical draw).
-__device__ inline void mg_check_damage(Ctx& cx, int ai, RngWin& rng) {
+// First half: when every threshold resource is held, pay the thresholds; returns the number of resources that can
+// lose a unit (>= 2 means the second half draws from the RNG), or -1 when the damage does not trigger.
+__device__ inline int mg_damage_pay(Ctx& cx, int ai) {
   const int* dc = cx.dc;
   DAgent* a = &cx.ag[ai];
   const int* gr = group_rec(dc, a->group);
   const int ot = gr[GR_OFF_DMG_THRESHOLD], orr = gr[GR_OFF_DMG_RESOURCES];
   const int nt = L_n(dc, ot), nr = L_n(dc, orr);
-  if (nt == 0 || nr == 0) return;
+  if (nt == 0 || nr == 0) return -1;
   for (int i = 0; i < nt; i++)
-    if ((int)a->amt[KV_k(dc, ot, i)] < (KV_v(dc, ot, i) & 0xFFFF)) return;
+    if ((int)a->amt[KV_k(dc, ot, i)] < (KV_v(dc, ot, i) & 0xFFFF)) return -1;
   for (int i = 0; i < nt; i++) inv_update(cx, ai, KV_k(dc, ot, i), -KV_v(dc, ot, i));
   int n_avail = 0;
-  double sum = 0.0;
-  for (int i = 0; i < nr; i++) {
-    int removable = (int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i);
-    if (removable > 0) {
-      n_avail++;
-      sum += (double)removable;
-    }
-  }
+  for (int i = 0; i < nr; i++)
+    if ((int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i) > 0) n_avail++;
+  return n_avail;
+}
+// Second half (only for agents whose first half returned >= 0).
+__device__ inline void mg_damage_apply(Ctx& cx, int ai, int n_avail, RngWin& rng) {
+  const int* dc = cx.dc;
+  DAgent* a = &cx.ag[ai];
+  const int* gr = group_rec(dc, a->group);
+  const int orr = gr[GR_OFF_DMG_RESOURCES];
+  const int nr = L_n(dc, orr);
   if (n_avail > 0) {
+    double sum = 0.0;
+    for (int i = 0; i < nr; i++) {
+      int removable = (int)a->amt[KV_k(dc, orr, i)] - KV_v(dc, orr, i);
+      if (removable > 0) sum += (double)removable;
+    }
     int sel = 0;
     if (n_avail >= 2) {
       const double p = rng.canonical();
@@ -984,6 +1004,10 @@ __device__ inline void mg_check_damage(Ctx& cx, int ai, RngWin& rng) {
   }
   mg_stat_add(cx, ai, cx.AS.damage_triggered(), 1);
 }
+__device__ inline void mg_check_damage(Ctx& cx, int ai, RngWin& rng) {
+  const int n_avail = mg_damage_pay(cx, ai);
+  if (n_avail >= 0) mg_damage_apply(cx, ai, n_avail, rng);
+}
 
 __device__ __forceinline__ int mg_inv_ntok(int amount, int base, int n_inv_tokens) {
   int n = 1;
@@ -1012,6 +1036,15 @@ template <class OUT>
 __device__ inline void mg_inventory_tokens(const int* dc, const DAgent* a, OUT& out) {  // observation_encoder.hpp:165-180
   const int base = dc[DC_TOKEN_BASE], nit = dc[DC_N_INV_TOKENS], ofi = dc[DC_OFF_FID_INV];
   const int ni = a->n_items;
+  if (base == 256) {  // the default base: digits are bytes (an integer division costs some forty instructions)
+    for (int i = 0; i < ni; i++) {
+      const int item = a->order[i];
+      const unsigned amount = a->amt[item];
+      out.put(dc[ofi + item * nit], (int)(amount & 0xFFu));
+      if (nit > 1 && (amount >> 8) != 0) out.put(dc[ofi + item * nit + 1], (int)(amount >> 8));  // amounts are uint16
+    }
+    return;
+  }
   for (int i = 0; i < ni; i++) {
     int item = a->order[i], amount = a->amt[item];
     out.put(dc[ofi + item * nit], (unsigned)amount % (unsigned)base);
