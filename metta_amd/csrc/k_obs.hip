@@ -7,7 +7,8 @@
 // ------------------------------------------------------------------------------------------------------------
 // BIG: grid tile and agent records are read in HBM (through L2); the token lists still live in LDS.
 template <bool DCL, bool BIG>
-__global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_kernel(KArgs a) {
+// BIG environments (hundreds of agents, one workgroup per CU at best) get 1024 threads: sixteen waves encode rows.
+__global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_kernel(KArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = blockDim.x, e = blockIdx.x + a.env_base;
   Lds l;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(MG_THREADS, BIG ? 1 : MG_OBS_WAVES) void mg_obs_ker
 
 
 void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st) {
-  if (big) hipLaunchKernelGGL((mg_obs_kernel<false, true>), dim3(n), dim3(MG_THREADS), lds, st, k);
+  if (big) hipLaunchKernelGGL((mg_obs_kernel<false, true>), dim3(n), dim3(MG_OBS_BIG_THREADS), lds, st, k);
   else if (dcl) hipLaunchKernelGGL((mg_obs_kernel<true, false>), dim3(n), dim3(MG_THREADS), lds, st, k);
   else hipLaunchKernelGGL((mg_obs_kernel<false, false>), dim3(n), dim3(MG_THREADS), lds, st, k);
 }

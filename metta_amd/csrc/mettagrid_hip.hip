@@ -488,11 +488,12 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   int dcw_obs = h->dc_lds ? k.dc_obs_words : 0;
   k.NAmax = NAmax; k.NCmax = NCmax; k.HW = HWp;
   h->lds_act = mg_act_lds_bytes(k, dcw != 0, big);
-  h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
+  const int obs_waves = (big ? MG_OBS_BIG_THREADS : MG_THREADS) / 64;
+  h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, obs_waves, dcw_obs, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   if (h->lds_act > LDS_MAX - 1024 || h->lds_obs > LDS_MAX) {
     h->dc_lds = false;
     h->lds_act = mg_act_lds_bytes(k, false, big);
-    h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, MG_THREADS / 64, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
+    h->lds_obs = mg_carve_obs<false>(nullptr, nullptr, hw_lds, c.A, NAmax, k.ROWB, obs_waves, 0, NOBJ, HEAP, NP, a_rec_obs, NCmax);
   }
   if (h->lds_act > LDS_MAX - 1024 || h->lds_obs > LDS_MAX)
     return fail("mg_set_maps: environment does not fit the 160 KiB LDS of one CU (act " + std::to_string(h->lds_act) +

@@ -11,6 +11,7 @@
 #include "mg_sim.h"
 
 #define MG_THREADS 256
+#define MG_OBS_BIG_THREADS 1024
 #ifndef MG_OBS_WAVES
 #define MG_OBS_WAVES 8
 #endif
