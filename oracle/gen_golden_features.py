@@ -1,0 +1,122 @@
+"""Feature-family fixtures through the REAL `convert_to_cpp_game_config` (run in the build container only).
+
+    make -C oracle ref && python oracle/gen_golden_features.py
+
+tests/golden/arena24_* and navigation4_* pin the config conversion for the arena / navigation presets only.  This
+script closes the gap for every other feature of the step path: for a list of seeds, `tests/fuzz_configs.rand_cfg`
+authors a feature-dense configuration in this repository's schema (vibe-triggered attack with defence / armor /
+weapon / loot / freeze, swaps, transfer, chests, damage, regeneration, partial usage, max_uses, multi-vibe protocols,
+limit modifiers, compass / goal tokens, odd windows, small token budgets, token bases).  Its dump is validated by the
+REFERENCE's pydantic `GameConfig` (so a field this schema names or defaults differently is an error here), converted
+by the reference's own `convert_to_cpp_game_config` (packages/mettagrid/python/src/mettagrid/config/
+mettagrid_c_config.py:30-577) and stepped by the reference's compiled core.  Recorded: map, seed, action stream and
+the expected per-step digests / final stats, and the configuration itself (this repository's schema, JSON).  The tests
+load that configuration and push it through metta_amd.compile + oracle + HIP: a wrong default or field mapping in compile.py (or in oracle/ref_bridge.py,
+whose hand-written mapping is cross-checked here against the real converter, step by step) shows up as a digest
+mismatch.
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from oracle.gen_golden import GOLD, digest, encode_names, install_reference_shims  # noqa: E402
+
+SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112]
+STEPS = 200
+
+
+def features_of(game) -> dict:
+    asm = [o for o in game.objects.values() if type(o).__name__ == "AssemblerConfig"]
+    return {
+        "attack": bool(game.actions.attack.enabled),
+        "transfer": bool(game.actions.transfer.enabled),
+        "chest": any(type(o).__name__ == "ChestConfig" for o in game.objects.values()),
+        "damage": any(a.damage is not None for a in game.agents),
+        "regen": game.inventory_regen_interval > 0 and any(a.inventory.regen_amounts for a in game.agents),
+        "partial_usage": any(a.allow_partial_usage for a in asm),
+        "max_uses": any(a.max_uses > 0 for a in asm),
+        "multi_vibe_protocol": any(len(p.vibes) > 1 for a in asm for p in a.protocols),
+        "limit_modifiers": any(l.modifiers for a in game.agents for l in a.inventory.limits.values()),
+        "chest_search": any(a.chest_search_distance > 0 for a in asm),
+        "move_costs": bool(game.actions.move.consumed_resources),
+        "token_base": int(game.obs.token_value_base),
+    }
+
+
+def main() -> None:
+    install_reference_shims()
+    from mettagrid.config.mettagrid_c_config import convert_to_cpp_game_config
+    from mettagrid.config.mettagrid_config import GameConfig as RefGameConfig
+    from mettagrid.mettagrid_c import MettaGrid
+
+    from metta_amd.compile import compile_game
+    from oracle.ref_bridge import RefEnv
+    from tests.fuzz_configs import fuzz_actions, rand_cfg
+
+    covered: dict[str, int] = {}
+    for seed in SEEDS:
+        cfg = rand_cfg(np.random.RandomState(seed), device_safe=True)
+        game = cfg.game
+        grid = np.asarray(game.map_builder.build(np.random.default_rng(seed)))
+        dump = game.model_dump(mode="json", exclude={"map_builder"})
+        ref_game = RefGameConfig.model_validate(dump)  # the reference's schema accepts (and re-defaults) our dump
+        c_cfg = convert_to_cpp_game_config(ref_game.model_dump())
+        A, T = game.num_agents, game.obs.num_tokens
+        env = MettaGrid(c_cfg, grid.tolist(), seed)
+        obs = np.zeros((A, T, 3), np.uint8)
+        term, trunc = np.zeros(A, bool), np.zeros(A, bool)
+        rew, act = np.zeros(A, np.float32), np.zeros(A, np.int32)
+        env.set_buffers(obs, term, trunc, rew, act)
+        bridge = RefEnv(game, grid, seed)  # the hand-written mapping of oracle/ref_bridge.py, side by side
+        assert np.array_equal(obs, bridge.obs), f"seed {seed}: ref_bridge differs from the real converter at step 0"
+        nA = len(compile_game(cfg, init_obs_passes=2).action_names)
+        rs = np.random.RandomState(seed + 7)
+        actions = np.stack([fuzz_actions(rs, game, nA) for _ in range(STEPS)])
+        od, rd, sd = (np.zeros(STEPS, np.uint64) for _ in range(3))
+        for t in range(STEPS):
+            act[:] = actions[t]
+            env.step()
+            bridge.step(actions[t])
+            assert np.array_equal(obs, bridge.obs) and np.array_equal(rew, bridge.rewards), (
+                f"seed {seed}: ref_bridge differs from the real converter at step {t + 1}"
+            )
+            od[t], rd[t] = digest(obs), digest(rew)
+            sd[t] = digest(np.array(env.action_success(), dtype=np.uint8))
+        stats = env.get_episode_stats()
+        assert stats == bridge.env.get_episode_stats(), f"seed {seed}: stats differ between the two conversions"
+        names, codes = encode_names(grid)
+        feats = features_of(game)
+        for k, v in feats.items():
+            if v and k != "token_base":
+                covered[k] = covered.get(k, 0) + 1
+        meta = {"seed": seed, "cell_names": names, "steps": STEPS, "stats": stats, "features": feats, "game": dump,
+                "terminated": bool(term.all()), "truncated": bool(trunc.all())}
+        np.savez_compressed(
+            GOLD / f"feature_{seed}.npz", meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), map_codes=codes,
+            actions=actions.astype(np.int32), obs0=bridge_obs0(game, grid, seed), obs_final=obs.copy(), obs_digest=od,
+            rew_digest=rd, succ_digest=sd, episode_rewards=np.array(env.get_episode_rewards(), dtype=np.float32),
+        )
+        print(f"wrote feature_{seed}.npz", {k: v for k, v in feats.items() if v})
+    print("feature coverage over the fixture set:", covered)
+    need = ["attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
+            "limit_modifiers", "chest_search"]
+    missing = [k for k in need if not covered.get(k)]
+    assert not missing, f"no fixture exercises {missing}: extend SEEDS"
+
+
+def bridge_obs0(game, grid, seed):
+    from oracle.ref_bridge import RefEnv
+
+    return RefEnv(game, grid, seed).obs.copy()
+
+
+if __name__ == "__main__":
+    main()

@@ -4,8 +4,9 @@
 `oracle/_ref/`; that file travels to the GPU box with the tree.  The reference's *Python* package does not
 travel, so this module rebuilds the pybind11 config objects from a `metta_amd.config.GameConfig` directly --
 the same field-by-field mapping as the reference's `convert_to_cpp_game_config`
-(`packages/mettagrid/python/src/mettagrid/config/mettagrid_c_config.py:30-577`), which `oracle/gen_golden.py`
-cross-checks against the real converter whenever /root/reference is present.
+(`packages/mettagrid/python/src/mettagrid/config/mettagrid_c_config.py:30-577`).  `oracle/gen_golden_features.py`
+cross-checks this mapping against the real converter, step by step, on twelve feature-dense configurations
+(attack, transfer, chests, damage, regeneration, partial usage, ...) when it writes tests/golden/feature_*.npz.
 
 Used by tests (HIP / oracle vs the real reference) and by bench.py's `cpu_baseline` leg (kind "reference").
 """

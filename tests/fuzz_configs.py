@@ -5,6 +5,7 @@ attack (defense / armor / weapon / loot / freeze / swap with frozen agents), tra
 vibes, min_agents, partial usage and max_uses, shared limits with modifiers, regeneration, initial inventories,
 compass / goal tokens, odd and even observation windows, tiny token budgets (dropped tokens) and token bases
 10/16/100/256.  `device_safe` is kept for callers; every feature generated here runs on the device path.
+A pure function of the seed (no iteration over string sets: their order changes with the process's hash seed).
 """
 
 from __future__ import annotations
@@ -110,7 +111,7 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridC
             if rs.randint(2):
                 regen["weapon"] = {rr(): int(rs.randint(-2, 3)), rr(): 1}
         rew = AgentRewards(
-            inventory={r: float(rs.choice([1, 0.5, 0.1, -0.25])) for r in set(rr() for _ in range(rs.randint(1, 4)))},
+            inventory={r: float(rs.choice([1, 0.5, 0.1, -0.25])) for r in sorted(set(rr() for _ in range(rs.randint(1, 4))))},
             inventory_max={R[0]: 2.0} if rs.randint(2) else {},
             stats={"action.move.success": 0.01, "action.failed": -0.001} if rs.randint(2) else {},
         )
@@ -136,7 +137,7 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridC
         defense_resources=rdict(2, 1, 2), armor_resources=rdict(2, 1, 2), weapon_resources=rdict(2, 1, 2),
         success=AttackOutcome(
             actor_inv_delta=rdict(2, -2, 2), target_inv_delta=rdict(2, -3, 1),
-            loot=list(set(rr() for _ in range(rs.randint(0, 3)))), freeze=int(rs.randint(0, 6)),
+            loot=sorted(set(rr() for _ in range(rs.randint(0, 3)))), freeze=int(rs.randint(0, 6)),
         ),
         vibes=["weapon"] + (["shield"] if rs.randint(2) else []),
         vibe_bonus={"armor": int(rs.randint(0, 4)), "heart": 1},

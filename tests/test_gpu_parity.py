@@ -163,6 +163,33 @@ def test_golden_arena(name):
     b.close()
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112])
+def test_golden_feature_families(seed):
+    """tests/golden/feature_<seed>.npz: configurations with attack / armor / loot / freeze, transfer, chests, damage,
+    regeneration, partial usage ... converted by the reference's REAL `convert_to_cpp_game_config` and stepped by its
+    core (oracle/gen_golden_features.py).  The HIP path, fed by metta_amd.compile, must reproduce the digests."""
+    from tests.test_oracle_golden import load_feature_fixture
+
+    z, meta, cfg, grid = load_feature_fixture(seed)
+    A = cfg.game.num_agents
+    b = _batch(cfg, [grid], 1, [seed], [0])
+    b.set_auto_reset(False)
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs0"])
+    acts = z["actions"]
+    for t in range(len(acts)):
+        b.step(acts[t])
+        assert digest(b.observations.cpu().numpy()) == int(z["obs_digest"][t]), f"seed {seed}: obs digest at step {t + 1}"
+        assert digest(b.rewards.cpu().numpy()) == int(z["rew_digest"][t]), f"seed {seed}: reward digest at step {t + 1}"
+        assert digest(b.action_success.cpu().numpy().astype(np.uint8)) == int(z["succ_digest"][t])
+    assert np.array_equal(b.observations.cpu().numpy(), z["obs_final"])
+    assert np.array_equal(b.episode_rewards.cpu().numpy(), z["episode_rewards"])
+    d = stats_equal(b.get_episode_stats(0), meta["stats"])
+    assert d is None, d
+    b.check_errors()
+    assert A == len(z["episode_rewards"])
+    b.close()
+
+
 def test_golden_navigation():
     z, meta = load_fixture("navigation4_seed3")
     cfg = make_navigation(4)

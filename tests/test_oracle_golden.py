@@ -110,3 +110,56 @@ def test_bridge_matches_reference_python_converter_shapes():
     assert len(comp.feature_names) == 12 + 2 * 10 + 2 * 10  # 52 feature ids
     assert comp.tag_names == ["agent", "armory", "assembler", "generator_red", "lasery", "mine_red", "wall"]
     assert comp.object_type_names[0] == "agent" and comp.object_type_names[1:] == sorted(cfg.game.objects.keys())
+
+
+FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112]
+
+
+def load_feature_fixture(seed):
+    """tests/golden/feature_<seed>.npz (oracle/gen_golden_features.py): a `rand_cfg(seed)` configuration pushed through
+    the reference's own pydantic schema, its real `convert_to_cpp_game_config` and its compiled core."""
+    import json
+    from pathlib import Path
+
+    from metta_amd.config import GameConfig, MettaGridConfig
+
+    z = np.load(Path(__file__).resolve().parent / "golden" / f"feature_{seed}.npz", allow_pickle=False)
+    meta = json.loads(bytes(z["meta"]).decode())
+    cfg = MettaGridConfig(game=GameConfig.model_validate(meta["game"]))  # the configuration travels with the fixture
+    grid = np.array(meta["cell_names"])[z["map_codes"]]
+    return z, meta, cfg, grid
+
+
+@pytest.mark.parametrize("seed", FEATURE_SEEDS)
+def test_oracle_vs_real_converter_fixture(seed):
+    """Pins metta_amd.compile (config -> tables) against the REAL converter for combat / chest / transfer / damage /
+    regen / partial-usage configs: the oracle, fed by compile_game, must reproduce what the reference produced from
+    its own conversion of the same configuration."""
+    from metta_amd.compile import compile_game
+    from oracle.mg_oracle import make_oracle_env
+    from tests.helpers import digest, stats_equal
+
+    z, meta, cfg, grid = load_feature_fixture(seed)
+    comp = compile_game(cfg, init_obs_passes=2)
+    o = make_oracle_env(comp, comp.encode_map(grid), seed)
+    assert np.array_equal(o.obs, z["obs0"])
+    acts = z["actions"]
+    for t in range(len(acts)):
+        o.step(acts[t])
+        assert digest(o.obs) == int(z["obs_digest"][t]), f"seed {seed}: obs digest at step {t + 1}"
+        assert digest(o.rewards) == int(z["rew_digest"][t]), f"seed {seed}: reward digest at step {t + 1}"
+        assert digest(o.action_success.astype(np.uint8)) == int(z["succ_digest"][t])
+    assert np.array_equal(o.obs, z["obs_final"])
+    assert np.array_equal(o.episode_rewards, z["episode_rewards"])
+    d = stats_equal(o.get_episode_stats(), meta["stats"])
+    assert d is None, d
+
+
+def test_feature_fixtures_cover_every_feature_family():
+    need = {"attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
+            "limit_modifiers", "chest_search", "move_costs"}
+    seen = set()
+    for seed in FEATURE_SEEDS:
+        _, meta, _, _ = load_feature_fixture(seed)
+        seen |= {k for k, v in meta["features"].items() if v and k != "token_base"}
+    assert need <= seen
