@@ -13,8 +13,9 @@ Environments shard across ranks as independent instances (no data-path collectiv
 collective is the RCCL all-reduce of the finished-episode summary vector every 128 steps.
 
 Prints ONE JSON line on rank 0.  `roofline`: algorithmic bytes per launch (1035 B per agent-step, SURVEY §8d:
-610 B boundary + ~425 B state) / mean kernel duration measured with HIP events on the launch stream over the timed
-steps (every 8th step is bracketed: the event pair is not free); `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
+610 B boundary + ~425 B state; one launch = one step = the fused kernel mg_step_fused*_kernel) / mean kernel duration
+measured with HIP events on the launch stream over the timed steps (every 8th step is bracketed: the event pair is not
+free); `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
 `cpu_baseline`: the reference's own compiled core (oracle/_ref, kind "reference") or the oracle port, stepped on
 the host cores over a bounded sample of the same workload, rank 0 / N=1 only.
 """
@@ -210,13 +211,18 @@ def main() -> None:
     dt = time.perf_counter() - t0
     kernel_ms = batch.profile_read(4096)
     batch.set_profiling(False)
-    # after the timed region: a short pass with events around the observation kernel alone (SURVEY 8d metric 2)
-    batch.set_profiling(2)
-    n_obs = min(args.steps, 100)
-    run(n_obs, args.warmup + args.steps)
-    sync_all()
-    obs_ms = batch.profile_read(4096)
-    batch.set_profiling(False)
+    step_path = batch.step_path()
+    fused = "fused" in step_path
+    obs_ms = np.zeros(0, np.float32)
+    if not fused:
+        # after the timed region: a short pass with events around the observation kernel alone (SURVEY 8d metric 2)
+        batch.set_profiling(2)
+        n_obs = min(args.steps, 100)
+        run(n_obs, args.warmup + args.steps)
+        sync_all()
+        obs_ms = batch.profile_read(4096)
+        batch.set_profiling(False)
+    batch.check_errors()  # an environment that left reference parity would void the measurement
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -265,12 +271,14 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel (the three launches of one step)",
+                "kernel": step_path + (" (one launch per step: actions, assembler uses, observations, rewards)" if fused else ""),
                 "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
                 "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
                 "kernel_ms_samples": int(len(kernel_ms)),
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "obs_kernel": {
+                "obs_kernel": None
+                if fused
+                else {
                     "ms_mean": float(obs_ms.mean()) if len(obs_ms) else None,
                     "algorithmic_bytes_per_launch": OBS_BYTES_PER_AGENT_STEP * E * A,
                     "achieved": OBS_BYTES_PER_AGENT_STEP * E * A / (float(obs_ms.mean()) * 1e-3) / 1e9 if len(obs_ms) else None,

@@ -87,6 +87,11 @@ int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream);
  * one GPU (different streams / threads) race; calls on one stream, or serialised by the caller, do not. */
 int mg_step_noalloc(mg_handle* h, const int32_t* device_actions, void* stream);
 
+/* Which kernels one mg_step launches for this handle's configuration and map pool (after mg_set_maps): the fused
+ * one-launch step for attack-free configurations with at most 64 agents, else the action + observation kernels.
+ * No reference counterpart (diagnostic; bench.py names the measured kernel with it). */
+const char* mg_step_path(mg_handle* h);
+
 /* Auto-reset policy used by mg_step: enabled (0/1) and how the next map is chosen: map_id += map_stride (mod P). */
 int mg_set_auto_reset(mg_handle* h, int enabled, int map_stride);
 

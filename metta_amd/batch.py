@@ -184,6 +184,10 @@ class MettaGridBatch:
             self.actions.copy_(t.reshape(-1).to(dtype=torch.int32), non_blocking=True)
         native.check(self.L.mg_step(self._h, self._stream()))
 
+    def step_path(self) -> str:
+        """Names of the kernels one step launches for this configuration (diagnostic)."""
+        return self.L.mg_step_path(self._h).decode()
+
     def set_auto_reset(self, enabled: bool, map_stride: int = 1) -> None:
         native.check(self.L.mg_set_auto_reset(self._h, int(enabled), int(map_stride)))
         self.map_stride = int(map_stride)

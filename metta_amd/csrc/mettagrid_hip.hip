@@ -858,6 +858,13 @@ int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
   return 0;
 }
 
+const char* mg_step_path(mg_handle* h) {
+  if (!h || !h->maps_set) return "";
+  if (h->fused) return h->no_modifiers ? "mg_step_fused_nomod_kernel" : "mg_step_fused_kernel";
+  if (h->k.fast) return "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel";
+  return "mg_act_kernel + mg_obs_kernel";
+}
+
 int mg_status_buffer(mg_handle* h, uint32_t** device_ptr, int32_t* n) {
   if (!h || !device_ptr || !n) return fail("mg_status_buffer: NULL argument");
   *device_ptr = h->k.status;

@@ -55,6 +55,7 @@ SYMBOLS = {
     "mg_status_buffer": (ct.c_int, [_vp, ct.POINTER(ct.POINTER(ct.c_uint32)), _i32p]),
     "mg_check_errors": (ct.c_int, [_vp, _vp]),
     "mg_debug_inject_error": (ct.c_int, [_vp, ct.c_int, ct.c_uint32]),
+    "mg_step_path": (ct.c_char_p, [_vp]),
     "mg_set_auto_reset": (ct.c_int, [_vp, ct.c_int, ct.c_int]),
     "mg_set_early_reset": (ct.c_int, [_vp, _u32p]),
     "mg_get_buffers": (ct.c_int, [_vp, ct.POINTER(MgBuffers)]),
