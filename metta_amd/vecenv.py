@@ -339,6 +339,120 @@ class MettaGridDeviceVecEnv:
             )
 
 
+class AsyncDeviceVecEnv:
+    """`async_factor` groups of environments behind one vecenv, served round-robin: what pufferlib's `Multiprocessing`
+    does with `batch_size < num_envs` (PUF/vector.py:415-503) -- `recv()` returns the group whose step has been issued
+    longest ago, with the agent ids of that group, and `send()` steps that group -- so that the policy's forward pass
+    on one group overlaps the environment step of the other.  Here every group is a `MettaGridDeviceVecEnv` with its
+    own HIP stream: `send()` only enqueues kernels, so the overlap comes from the stream, not from worker processes.
+    Environment i of the whole set gets seed `seed + i` (PUF/vector.py:90,382)."""
+
+    def __init__(self, cfg: MettaGridConfig, num_envs: int, batch_size: int, device: int = 0, seed: int = 0, **kw):
+        if num_envs % batch_size != 0:
+            raise APIUsageError("num_envs must be divisible by batch_size")  # PUF/vector.py:287-288
+        import torch
+
+        self.groups = [
+            MettaGridDeviceVecEnv(cfg, batch_size, device=device, seed=seed + g * batch_size, **kw)
+            for g in range(num_envs // batch_size)
+        ]
+        g0 = self.groups[0]
+        self.num_environments = int(num_envs)
+        self.agents_per_env = g0.agents_per_env
+        self.agents_per_batch = g0.num_agents
+        self.num_agents = self.agents_per_batch * len(self.groups)
+        self.single_observation_space, self.single_action_space = g0.single_observation_space, g0.single_action_space
+        self.observation_space, self.action_space = g0.observation_space, g0.action_space
+        self.policy_env_info, self.cfg = g0.policy_env_info, cfg
+        self.emulated, self.driver_env = False, g0
+        self._streams = [torch.cuda.Stream(device=g0.batch.device) for _ in self.groups]
+        self._agent_ids = [g.agent_ids + k * self.agents_per_batch for k, g in enumerate(self.groups)]
+        self._next = 0
+        self._seed = seed
+        self.flag = RESET
+
+    @property
+    def num_envs(self) -> int:
+        return self.num_agents
+
+    def async_reset(self, seed: Optional[int] = None) -> None:
+        if seed is not None:
+            self._seed = int(seed)
+        for k, g in enumerate(self.groups):
+            g.async_reset(self._seed + k * g.num_environments)
+        self._next = 0
+        self.flag = RECV
+
+    def recv(self):
+        if self.flag != RECV:
+            raise APIUsageError("Call reset before stepping")
+        self.flag = SEND
+        import torch
+
+        k = self._next
+        # the caller's stream waits for this group's last step; the other groups keep running on their own streams
+        torch.cuda.current_stream(self.groups[k].batch.device).wait_stream(self._streams[k])
+        o, r, d, t, ta, infos, _, m = self.groups[k].recv()
+        return o, r, d, t, ta, infos, self._agent_ids[k], m
+
+    def send(self, actions) -> None:
+        if self.flag != SEND:
+            raise APIUsageError("Call (async) reset + recv before sending")
+        self.flag = RECV
+        import torch
+
+        k = self._next
+        st = self._streams[k]
+        st.wait_stream(torch.cuda.current_stream(self.groups[k].batch.device))  # the actions were produced there
+        with torch.cuda.stream(st):
+            self.groups[k].send(actions)
+        self._next = (k + 1) % len(self.groups)
+
+    def reset(self, seed: int = 42):
+        self.async_reset(seed)
+        obs, _, _, _, _, infos, _, _ = self.recv()
+        return obs, infos
+
+    def step(self, actions):
+        self.send(actions)
+        obs, rew, term, trunc, _, infos, _, _ = self.recv()
+        return obs, rew, term, trunc, infos
+
+    def flush_infos(self) -> list:
+        out = []
+        for g in self.groups:
+            out.extend(g.flush_infos())
+        return out
+
+    def close(self) -> None:
+        for g in self.groups:
+            g.close()
+
+
+def make_vecenv(
+    cfg: MettaGridConfig,
+    vectorization: str = "device",
+    num_envs: int = 1,
+    batch_size: Optional[int] = None,
+    num_workers: int = 1,
+    device: int = 0,
+    seed: int = 0,
+    **kwargs,
+):
+    """`make_vecenv` of metta/rl/vecenv.py:53-101 for the device path: same arguments and checks (`num_envs >= 1`,
+    `batch_size` defaults to `num_envs`; `num_workers` is accepted and unused: there are no worker processes).
+    `vectorization` must be "device"; "serial" / "multiprocessing" name the reference's CPU backends, which this
+    package deliberately does not contain."""
+    if vectorization != "device":
+        raise ValueError("Invalid --vector (this package provides the 'device' backend only).")
+    if num_envs < 1:
+        raise ValueError(f"num_envs must be at least 1, got {num_envs}")
+    batch_size = batch_size or num_envs
+    if batch_size == num_envs:
+        return MettaGridDeviceVecEnv(cfg, num_envs, device=device, seed=seed, **kwargs)
+    return AsyncDeviceVecEnv(cfg, num_envs, batch_size, device=device, seed=seed, **kwargs)
+
+
 @dataclass
 class BatchInfo:
     target_batch_size: int
@@ -347,20 +461,50 @@ class BatchInfo:
 
 
 class DeviceTrainingEnvironment:
-    """`TrainingEnvironment` (metta/rl/training/training_environment.py:85-118) over the device vecenv."""
+    """`VectorizedTrainingEnvironment` (metta/rl/training/training_environment.py:121-275) over the device vecenv.
 
-    def __init__(self, cfg: MettaGridConfig, num_envs: int, device: int = 0, seed: int = 0, **vec_kwargs):
-        self._vecenv = MettaGridDeviceVecEnv(cfg, num_envs, device=device, seed=seed, **vec_kwargs)
+    Either `num_envs` directly, or the reference's sizing: `forward_pass_minibatch_target_size` agents per forward pass
+    and `async_factor` groups (`calculate_batch_sizes`, metta/rl/training/batch.py:6-21, with one "worker")."""
+
+    def __init__(
+        self,
+        cfg: MettaGridConfig,
+        num_envs: Optional[int] = None,
+        device: int = 0,
+        seed: int = 0,
+        forward_pass_minibatch_target_size: int = 4096,
+        async_factor: int = 1,
+        **vec_kwargs,
+    ):
+        from metta_amd.training import calculate_batch_sizes
+
+        A = cfg.game.num_agents
+        if num_envs is None:
+            self._target_batch_size, self._batch_size, self._num_envs = calculate_batch_sizes(
+                forward_pass_minibatch_target_size, A, 1, async_factor
+            )
+        else:
+            if num_envs % async_factor != 0:
+                raise ValueError("num_envs must be divisible by async_factor")
+            self._num_envs, self._batch_size = num_envs, num_envs // async_factor
+            self._target_batch_size = self._batch_size
+        self._vecenv = make_vecenv(
+            cfg, "device", num_envs=self._num_envs, batch_size=self._batch_size, device=device, seed=seed, **vec_kwargs
+        )
         self._vecenv.async_reset(seed)
-        self._num_envs = num_envs
 
     def close(self) -> None:
         self._vecenv.close()
 
     def get_observations(self):
         o, r, d, t, ta, info, env_id, mask = self._vecenv.recv()
-        training_env_id = slice(0, self._vecenv.num_agents)
-        num_steps = self._vecenv.num_agents  # masks are all ones (BIND/mettagrid_c.cpp:983-995)
+        n = o.shape[0]
+        if isinstance(self._vecenv, AsyncDeviceVecEnv):
+            start = self._vecenv._next * n  # the group recv() just served (contiguous agent ids, like zero_copy=True)
+        else:
+            start = 0
+        training_env_id = slice(start, start + n)
+        num_steps = n  # masks are all ones (BIND/mettagrid_c.cpp:983-995): no device read needed to count them
         return o, r, d, t, ta, info, training_env_id, mask, num_steps
 
     def send_actions(self, actions) -> None:
@@ -368,8 +512,7 @@ class DeviceTrainingEnvironment:
 
     @property
     def batch_info(self) -> BatchInfo:
-        n = self._vecenv.num_agents
-        return BatchInfo(target_batch_size=n, batch_size=self._num_envs, num_envs=self._num_envs)
+        return BatchInfo(target_batch_size=self._target_batch_size, batch_size=self._batch_size, num_envs=self._num_envs)
 
     @property
     def single_action_space(self):
@@ -384,8 +527,12 @@ class DeviceTrainingEnvironment:
         return self._vecenv.policy_env_info
 
     @property
-    def vecenv(self) -> MettaGridDeviceVecEnv:
+    def vecenv(self):
         return self._vecenv
+
+    @property
+    def driver_env(self):
+        return self._vecenv.driver_env
 
     @property
     def total_parallel_agents(self) -> int:
