@@ -58,6 +58,13 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
  * token's map centre, mettagrid_c.cpp:483-517) uses the size of the map an environment currently plays. */
 int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths);
 
+/* Per-map episode length: max_steps[P] (0 = the configuration's `max_steps`), host array; NULL restores the
+ * configuration's value for every map.  The reference gives every map of an evaluation suite its own environment
+ * config whose only difference is `game.max_steps` (recipes/experiment/navigation.py:32-59, cfg.py NAVIGATION_EVALS);
+ * the termination test and the episode-completion token (mettagrid_c.cpp:433-447,667-677) then use the value of the map
+ * an environment plays.  Call after mg_set_maps (a new pool clears it). */
+int mg_set_map_max_steps(mg_handle* h, const int32_t* max_steps);
+
 /* `MettaGrid.map_height / map_width` (mettagrid_c.cpp:1040-1041) of map `map_id` of the pool. */
 int mg_map_dims(mg_handle* h, int map_id, int32_t* height, int32_t* width);
 

@@ -122,6 +122,7 @@ class MettaGridBatch:
         if any(e.ndim != 2 for e in enc):
             raise RuntimeError("maps must be 2-D")
         self.map_pool = enc
+        self.map_max_steps = None
         self.map_dims = np.array([e.shape for e in enc], dtype=np.int32)  # [P][2] = (height, width)
         # the reference's read-only map_height / map_width; for a mixed pool: the largest (see map_dims, env_map_dims)
         self.map_height, self.map_width = int(self.map_dims[:, 0].max()), int(self.map_dims[:, 1].max())
@@ -135,6 +136,19 @@ class MettaGridBatch:
             native.check(
                 self.L.mg_set_maps_ragged(self._h, _p(flat, ct.c_uint8), len(enc), _p(hs, ct.c_int32), _p(ws, ct.c_int32))
             )
+
+    def set_map_max_steps(self, max_steps: Optional[Sequence[int]]) -> None:
+        """Episode length per map of the pool (0 = the configuration's `max_steps`); None clears it.  The reference's
+        evaluation suites give each map its own `game.max_steps` (recipes/experiment/navigation.py:32-59)."""
+        if max_steps is None:
+            native.check(self.L.mg_set_map_max_steps(self._h, None))
+            self.map_max_steps = None
+            return
+        ms = np.ascontiguousarray(max_steps, dtype=np.int32)
+        if ms.shape != (len(self.map_pool),):
+            raise RuntimeError("max_steps must have one entry per map of the pool")
+        native.check(self.L.mg_set_map_max_steps(self._h, _p(ms, ct.c_int32)))
+        self.map_max_steps = ms
 
     def env_map_dims(self, map_id: int) -> tuple[int, int]:
         """(height, width) of map `map_id` of the pool (reference: `MettaGrid.map_height / map_width`)."""

@@ -419,7 +419,8 @@ __device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& 
 // values of the previous phase cannot be kept alive across the phase boundary (they would be spilled there: the phases
 // together need several times the registers any one of them does).
 template <bool DCL>
-__device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id) {
+__device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id,
+                                               int max_steps) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __attribute__((address_space(4))) KArgs* ka =
       (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -435,6 +436,7 @@ __device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* 
   if (DCL) a.dc = l.dc;
   a.H = H;
   a.W = W;
+  a.max_steps = max_steps;
 }
 
 template <bool DCL>
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   const int tid = threadIdx.x, nt = MG_FUSED_THREADS;
   const int lane = tid & 63, wave = tid >> 6;
   DEnv env;
-  int H, W, act = 0, NW_, actor = 0;
+  int H, W, act = 0, NW_, actor = 0, max_steps;
   uint32_t mt_raw = 0;
 
   // ---- P0: stage -----------------------------------------------------------------------------------------------
@@ -475,6 +477,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
     mg_use_map(a, env.map_id);
     H = a.H;
     W = a.W;
+    max_steps = a.max_steps;
     NW_ = a.NWIN < 64 ? a.NWIN : 64;
     const uint32_t* mt = a.mt + (size_t)e * 624;
     const bool need_twist = (int)env.mt_idx + NW_ > 624;  // block-uniform
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   if (wave == actor) {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
     const int e = blockIdx.x + a.env_base;
     uint32_t w = 0;
     {
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(2);
     const int n_uses = l.flags[3];
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
     __syncthreads();  // (the use scratch becomes the token lists)
     mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
     __syncthreads();
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
     const int e = blockIdx.x + a.env_base;
     if (!(a.diag & 16)) mg_encode_all<uint8_t, false, true>(a, l, e, env.step, l.exec, true, tid, nt);
     __syncthreads();
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs b;
     Lds l;
-    mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id);
+    mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id, max_steps);
     const int e = blockIdx.x + b.env_base;
     if (wave == 0) {
       mg_fused_token_stats(b, l, lane);

@@ -237,6 +237,8 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (max_draws > 624) return fail("mg_create: too many agents for the RNG window");
   k.ROWB = (int)mg_align16((size_t)c.T * 3) + 16;  // + the row's 16-byte phase in HBM (mg_encode_all)
   k.auto_reset = 1; k.map_stride = 1;
+  k.max_steps = k.max_steps_cfg = c.max_steps;
+  k.map_max_steps = nullptr;
   {
     // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
     bool ok = c.A <= 64 && c.regen_interval == 0 && !has_damage && c.chests.empty();
@@ -604,6 +606,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     k.t_agents = t_agents; k.t_asms = t_asms; k.t_astats = t_astats; k.t_atouched = t_atouched;
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
+  k.map_max_steps = nullptr;  // (freed with the old pool)
   h->maps_set = true;
   h->needs_reset = true;
   if (k.map_stride >= num_maps) k.map_stride %= num_maps;
@@ -618,6 +621,24 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
 
 int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths) {
   return mg_set_maps_impl(h, maps, num_maps, heights, widths);
+}
+
+int mg_set_map_max_steps(mg_handle* h, const int32_t* max_steps) {
+  if (!h) return fail("mg_set_map_max_steps: NULL handle");
+  if (!h->maps_set) return fail("mg_set_map_max_steps: call mg_set_maps first");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (!max_steps) {
+    h->k.map_max_steps = nullptr;
+    return 0;
+  }
+  for (int m = 0; m < h->k.P; m++)
+    if (max_steps[m] < 0) return fail("mg_set_map_max_steps: negative episode length");
+  int* d = nullptr;
+  if (dalloc(h, &d, (size_t)h->k.P, true)) return 1;
+  HIPCHK(hipMemcpy(d, max_steps, (size_t)h->k.P * 4, hipMemcpyHostToDevice));
+  h->k.map_max_steps = d;
+  return 0;
 }
 
 int mg_map_dims(mg_handle* h, int map_id, int32_t* height, int32_t* width) {

@@ -41,6 +41,8 @@ struct KArgs {
   const float* map_objcount;  // [P][n_cells]
   uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
+  const int* map_max_steps;   // [P] episode length of each map (0 = the configuration's), or null: every map the configuration's
+  int max_steps, max_steps_cfg;  // the current environment's / the configuration's max_steps
   int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
   int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
   int NWINCELLS;           // cells of the observation window (obs_h * obs_w)
@@ -133,6 +135,12 @@ __device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
   const int2 d = a.map_dims[map_id];
   a.H = d.x;
   a.W = d.y;
+  int ms = a.max_steps_cfg;
+  if (a.map_max_steps) {
+    const int m = a.map_max_steps[map_id];
+    if (m > 0) ms = m;
+  }
+  a.max_steps = ms;
 }
 
 // FILL = false: sizes only (host).  A compile-time switch rather than `if (l)`: a null test on the kernel's Lds
@@ -325,7 +333,7 @@ __device__ inline GlobalTok mg_global_tok(const KArgs& a, uint32_t step, int lan
   g.f = 0; g.v = 0; g.is_action = false;
   int n = 0;
   if (dc[DC_G_COMPLETION]) {
-    const int ms = dc[DC_MAX_STEPS];
+    const int ms = a.max_steps;  // (the map's, where the pool carries per-map episode lengths)
     int pct = 0;
     if (ms > 0) pct = step >= (uint32_t)ms ? 255 : (int)((256u * step / (uint32_t)ms) & 0xFF);
     if (lane == n) { g.f = (uint32_t)dc[DC_FID0 + MG_F_COMPLETION]; g.v = (uint32_t)pct; }
@@ -785,7 +793,7 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
   const MgAgentSlots AS{a.R, a.NG};
   bool end_now = false, trunc_now = false;
   {
-    int ms = dc[DC_MAX_STEPS];
+    int ms = a.max_steps;
     if (ms > 0 && env.step >= (uint32_t)ms) {
       end_now = true;
       trunc_now = dc[DC_TRUNCATES] != 0;
