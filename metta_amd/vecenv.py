@@ -88,6 +88,7 @@ class MettaGridDeviceVecEnv:
         seed: int = 0,
         early_reset: bool = True,
         map_seed: int = 0,
+        init_obs_passes: int = 2,
     ):
         self.cfg = cfg
         self.policy_env_info = PolicyEnvInterface.from_mg_cfg(cfg)
@@ -95,7 +96,9 @@ class MettaGridDeviceVecEnv:
         if maps is None:
             rng = np.random.default_rng(map_seed)
             maps = [game.map_builder.build(rng) for _ in range(num_maps)]
-        self.compiled = compile_game(cfg, init_obs_passes=2)  # the Puffer path: ctor + set_buffers
+        # 2 = the Puffer path: the step-0 observations are computed by the ctor and again by set_buffers;
+        # 1 = a bare `Simulation` without shared buffers
+        self.compiled = compile_game(cfg, init_obs_passes=init_obs_passes)
         self.batch = MettaGridBatch(cfg, num_envs, maps, device=device, compiled=self.compiled)
         self.batch.set_auto_reset(True, 1)
         self.num_environments = int(num_envs)
@@ -118,6 +121,7 @@ class MettaGridDeviceVecEnv:
         self.flag = RESET
         self._episodes_seen = np.zeros(self.num_environments, dtype=np.int64)
         self._per_label_rewards: dict[str, float] = {}
+        self._per_label_chest_deposits: dict[str, float] = {}
         self._done_prev = None
         # How finished episodes reach `infos`:
         #   0 (default)  no host synchronisation in send(): after each step the 16-byte device status word (error bits,
@@ -294,6 +298,7 @@ class MettaGridDeviceVecEnv:
                     "game": stats["game"],
                     "agent": agent,
                     "per_label_rewards": dict(self._per_label_rewards),
+                    "per_label_chest_deposits": self._chest_deposits(stats["game"]),
                     "attributes": {
                         "seed": info["seed"],
                         "map_w": int(b.map_dims[info["map_id"], 1]),
@@ -305,6 +310,11 @@ class MettaGridDeviceVecEnv:
                 }
             )
 
+
+    def _chest_deposits(self, game_stats: dict) -> dict:
+        # stats_tracker.py:58-61: hearts deposited in chests, per mission label
+        self._per_label_chest_deposits[self._label] = game_stats.get("chest.heart.deposited", 0.0)
+        return dict(self._per_label_chest_deposits)
 
     def _collect_finished(self) -> None:
         """Low-sync variant: episodes whose counter advanced since the last poll, from the snapshot the act kernel
@@ -330,6 +340,7 @@ class MettaGridDeviceVecEnv:
                     "game": stats["game"],
                     "agent": {k: v / A for k, v in agent.items()},
                     "per_label_rewards": dict(self._per_label_rewards),
+                    "per_label_chest_deposits": self._chest_deposits(stats["game"]),
                     "attributes": {
                         "seed": int(table[e, 2]), "map_w": int(b.map_dims[prev_map, 1]),
                         "map_h": int(b.map_dims[prev_map, 0]), "steps": steps,

@@ -321,3 +321,46 @@ def test_set_maps_again_requires_full_reset():
         b.set_auto_reset(True, -1)
     b.check_errors()
     b.close()
+
+
+@pytest.mark.parametrize("case_name", ["arena24", "navigation4"])
+@pytest.mark.parametrize("stats_every", [1, 0])
+def test_episode_infos_equal_the_reference_stats_tracker(case_name, stats_every):
+    """tests/golden/episode_infos.json (oracle/gen_golden_infos.py): the `infos` dict the reference's StatsTracker built at
+    episode end (python/src/mettagrid/envs/stats_tracker.py:26-107).  Key for key, value for value; excluded, because they
+    are wall-clock readings: `attributes.completion_time` (presence checked) and the `timing_*` sections (not produced:
+    there is no per-env Python to time)."""
+    import json
+    from pathlib import Path
+
+    from metta_amd.builder import make_navigation
+    from metta_amd.vecenv import MettaGridDeviceVecEnv
+
+    cases = json.loads((Path(__file__).resolve().parent / "golden" / "episode_infos.json").read_text())["cases"]
+    case = next(c for c in cases if c["name"] == case_name)
+    cfg = make_arena(24) if case_name == "arena24" else make_navigation(4)
+    cfg.game.max_steps = case["max_steps"]
+    cfg.label = case["label"]
+    grid = np.array(case["cell_names"])[np.array(case["map_codes"], np.uint8).reshape(case["map_shape"])]
+    A = cfg.game.num_agents
+    v = MettaGridDeviceVecEnv(cfg, 1, maps=[grid], device=0, seed=case["seed"], early_reset=False, init_obs_passes=1)
+    v.stats_every = stats_every
+    v.async_reset(case["seed"])
+    rs = np.random.RandomState(case["seed"])
+    got = []
+    for _ in range(case["steps_run"] + 2):
+        got.extend(v.recv()[5])
+        v.send(rs.randint(0, 5, size=A).astype(np.int32))
+    got.extend(v.recv()[5])
+    got.extend(v.flush_infos())
+    ours, ref = got[0], case["infos"]
+    assert set(ours) == set(ref), (sorted(ours), sorted(ref))
+    assert set(ours["game"]) == set(ref["game"]) and set(ours["agent"]) == set(ref["agent"])
+    for sect in ("game", "agent", "per_label_rewards", "per_label_chest_deposits"):
+        for k, x in ref[sect].items():
+            assert ours[sect][k] == pytest.approx(x, rel=1e-6, abs=0), f"{sect}.{k}: {ours[sect][k]} vs {x}"
+    ra, oa = dict(ref["attributes"]), dict(ours["attributes"])
+    assert "completion_time" in ra and "completion_time" in oa
+    ra.pop("completion_time"), oa.pop("completion_time")
+    assert oa == ra, (oa, ra)
+    v.close()
