@@ -152,6 +152,7 @@ def main() -> None:
 
     from metta_amd.batch import MettaGridBatch
     from metta_amd.builder import make_arena
+    from metta_amd.dist import bench_shard
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -167,8 +168,7 @@ def main() -> None:
     E, A = args.envs, AGENTS
     cfg = make_arena(A)
     pool = _load_pool()
-    seeds = [rank * E + e for e in range(E)]  # pufferlib convention: env i gets seed base + i (vector.py:90)
-    map_ids = [(rank * E + e) % len(pool) for e in range(E)]
+    seeds, map_ids = bench_shard(rank, E, len(pool))  # env g: seed g (pufferlib vector.py:90), map g mod pool
     batch = MettaGridBatch(cfg, E, pool, device=local_rank, init_obs_passes=2, seeds=seeds, map_ids=map_ids)
     batch.set_auto_reset(True, 1)
     # desynchronise episode phases like the reference's EarlyResetHandler (early_reset_handler.py:6-20)

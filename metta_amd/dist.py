@@ -23,6 +23,14 @@ def shard_seeds(base_seed: int, num_envs_total: int, rank: int, world: int) -> n
     return ((np.arange(lo, hi, dtype=np.int64) + base_seed) & 0xFFFFFFFF).astype(np.uint32)
 
 
+def bench_shard(rank: int, envs_per_rank: int, pool_len: int, base_seed: int = 0) -> tuple[list[int], list[int]]:
+    """Weak-scaling shard of `bench.py`: rank r owns the global env ids [r*E, (r+1)*E); env g gets seed base + g
+    (PUF/vector.py:90) and map g mod pool_len, so N ranks x E envs are exactly one N*E-env handle cut into blocks."""
+    lo = rank * envs_per_rank
+    ids = range(lo, lo + envs_per_rank)
+    return [(base_seed + g) & 0xFFFFFFFF for g in ids], [g % pool_len for g in ids]
+
+
 def all_reduce_summary(summary: np.ndarray, device=None) -> np.ndarray:
     """Sum the per-rank summary vector [episodes, sum(len), sum(reward), game stat sums...] over all ranks."""
     import torch
