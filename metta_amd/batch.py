@@ -62,6 +62,19 @@ def _p(a: np.ndarray, t):
     return a.ctypes.data_as(ct.POINTER(t))
 
 
+class _DevicePool:
+    """`map_pool` of a device-generated pool: maps are read back from HBM on demand (they change as slots refresh)."""
+
+    def __init__(self, batch, num_maps: int):
+        self._batch, self._n = batch, int(num_maps)
+
+    def __len__(self) -> int:
+        return self._n
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        return self._batch.get_map(int(i) % self._n)
+
+
 class MettaGridBatch:
     def __init__(
         self,
@@ -113,7 +126,13 @@ class MettaGridBatch:
 
     # ---- maps / reset / step ---------------------------------------------------------------------------
     def set_maps(self, maps: Sequence) -> None:
-        """`maps`: sequence of 2-D arrays, either uint8 cell codes or cell-name grids (reference `GameMap.grid`)."""
+        """`maps`: sequence of 2-D arrays, either uint8 cell codes or cell-name grids (reference `GameMap.grid`), or a
+        `metta_amd.mapgen.GeneratedMaps` (the pool is then drawn on the device, see `set_generated_maps`)."""
+        from .mapgen import GeneratedMaps
+
+        if isinstance(maps, GeneratedMaps):
+            return self.set_generated_maps(maps.spec, maps.num_maps, maps.seed)
+        self.generated = False
         enc = []
         for m in maps:
             arr = np.asarray(m)
@@ -136,6 +155,38 @@ class MettaGridBatch:
             native.check(
                 self.L.mg_set_maps_ragged(self._h, _p(flat, ct.c_uint8), len(enc), _p(hs, ct.c_int32), _p(ws, ct.c_int32))
             )
+
+    def set_generated_maps(self, spec, num_maps: int, seed: int = 0) -> None:
+        """A pool of `num_maps` slots drawn on the device from `spec` (`metta_amd.mapgen.DeviceMapSpec`): the
+        reference's `RandomMapBuilder` / MapGen `Random` scene distribution (random_map.py:29-96, scenes/random.py:19-69)
+        without a host copy.  `refresh_maps()` redraws used, idle slots."""
+        e = spec.encode(self.compiled)
+        native.check(
+            self.L.mg_set_generated_maps(
+                self._h, e["height"], e["width"], e["fill_code"], len(e["rooms"]), _p(e["rooms"], ct.c_int32),
+                _p(e["room_sym_begin"], ct.c_int32), _p(e["sym_code"], ct.c_int32), _p(e["sym_count"], ct.c_int32),
+                int(num_maps), int(seed) & 0xFFFFFFFFFFFFFFFF,
+            )
+        )  # fmt: skip
+        self.generated = True
+        self.map_max_steps = None
+        self.map_dims = np.tile(np.array([[e["height"], e["width"]]], dtype=np.int32), (int(num_maps), 1))
+        self.map_height, self.map_width = e["height"], e["width"]
+        self.map_pool = _DevicePool(self, num_maps)
+
+    def refresh_maps(self, force: bool = False) -> None:
+        """Redraw, on the launch stream and without a host sync, every slot that an episode has used since it was
+        drawn and that no environment is on now (`force`: every slot; the environments then need a `reset`).  With
+        2E slots and `set_auto_reset(True, map_stride=E)` each environment alternates between two slots, and a refresh
+        once per episode gives every episode a new map, like the reference's per-episode `map_builder.build()`
+        (simulator.py:264-267)."""
+        native.check(self.L.mg_refresh_maps(self._h, int(bool(force)), self._stream()))
+
+    def get_map(self, map_id: int) -> np.ndarray:
+        """uint8 cell codes of slot `map_id` of a device-generated pool (host copy; synchronises the stream)."""
+        out = np.zeros((self.map_height, self.map_width), np.uint8)
+        native.check(self.L.mg_get_map(self._h, int(map_id), _p(out, ct.c_uint8), self._stream()))
+        return out
 
     def set_map_max_steps(self, max_steps: Optional[Sequence[int]]) -> None:
         """Episode length per map of the pool (0 = the configuration's `max_steps`); None clears it.  The reference's

@@ -8,6 +8,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
 #ifdef MG_ISA_LITE  // ISA inspection builds (tools/isa.sh): keep only the kernel under study
   return;
 #endif
+  if (a.reset_count && (int)blockIdx.x >= *a.reset_count) return;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int e = a.reset_envs ? a.reset_envs[blockIdx.x] : (int)blockIdx.x;
   Lds l;

@@ -25,6 +25,7 @@
 #include "../../include/mettagrid_hip.h"
 #include "mg_blob.h"
 #include "mg_kernels.h"
+#include "mg_mapgen.h"
 
 __global__ void mg_end_episode_kernel(KArgs a, int env) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -111,7 +112,8 @@ static std::string mg_error_text(uint32_t bits) {
   if (bits & 1u) t += "RNG window overflow (more MT19937 outputs needed in one step than staged); ";
   if (bits & 4u) t += "frozen agent on the wave-parallel act path (configuration misclassified as attack-free); ";
   if (bits & 8u) t += "more than 24 chests within an assembler's search distance (work list overflow); ";
-  if (bits & ~13u) t += "unknown error bits " + std::to_string(bits & ~13u) + "; ";
+  if (bits & 16u) t += "device map generator produced a map that does not match the pool (agents / assembler / chest counts); ";
+  if (bits & ~29u) t += "unknown error bits " + std::to_string(bits & ~29u) + "; ";
   if (!t.empty()) t.resize(t.size() - 2);
   return t;
 }
@@ -145,6 +147,14 @@ struct mg_handle {
   int* d_list = nullptr;       // scratch for reset lists [3][E]
   int* d_inv = nullptr;        // scratch for set_inventory [2][MGD_MAX_R]
   uint8_t* masks = nullptr;    // all ones (reference: mettagrid_c.cpp:983-995)
+  // episode-start template builds (mg_set_maps, mg_refresh_maps): the reset kernel's arguments aimed at the templates
+  KArgs kt;
+  int* d_iota = nullptr;       // [P] 0 .. P-1
+  // device map generator (mg_set_generated_maps / mg_refresh_maps)
+  bool generated = false;
+  MapGenArgs gen;
+  uint32_t* d_inuse = nullptr;
+  bool in_set_generated = false;
 };
 
 // ---- static scratch of the allocation-free step (mg_step_noalloc) ---------------------------------------------
@@ -559,54 +569,53 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (dalloc(h, &t_atouched, PA * k.TW, true)) return 1;
     if (dalloc(h, &t_gstats, P * k.SG, true)) return 1;
     if (dalloc(h, &t_gtouched, P * k.GW, true)) return 1;
-    std::vector<void*> tmp;
-    auto talloc = [&](size_t bytes) -> void* {
-      void* q = nullptr;
-      if (hipMalloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr;
-      (void)hipMemset(q, 0, bytes ? bytes : 1);
-      tmp.push_back(q);
-      return q;
-    };
+    // (the reset kernel's other outputs -- observations, flags, RNG -- land in throw-away buffers kept with the pool,
+    // so that mg_refresh_maps can rebuild templates without allocating)
     KArgs kt = k;
     kt.E = (int)P;
-    kt.env = (DEnv*)talloc(P * sizeof(DEnv));
-    kt.mt = (uint32_t*)talloc(P * 624 * 4);
+    uint32_t* d_seeds = nullptr;
+    int* d_maps = nullptr;
+    if (dalloc(h, &kt.env, P, true)) return 1;
+    if (dalloc(h, &kt.mt, P * 624, true)) return 1;
     kt.mt_init = nullptr;
     kt.chests = t_chests;
     kt.agents = t_agents; kt.asms = t_asms; kt.astats = t_astats; kt.atouched = t_atouched;
     kt.gstats = t_gstats; kt.gtouched = t_gtouched;
-    kt.obs = (uint8_t*)talloc(PA * c.T * 3);
-    kt.rewards = (float*)talloc(PA * 4);
-    kt.ep_rewards = (float*)talloc(PA * 4);
-    kt.term = (uint8_t*)talloc(PA);
-    kt.trunc = (uint8_t*)talloc(PA);
-    kt.success = (uint8_t*)talloc(PA);
-    uint32_t* d_seeds = (uint32_t*)talloc(P * 4);
-    int* d_maps = (int*)talloc(P * 4);
-    bool okalloc = kt.env && kt.mt && kt.obs && kt.rewards && kt.ep_rewards && kt.term && kt.trunc && kt.success && d_seeds && d_maps;
-    int rc = 0;
-    if (!okalloc) {
-      rc = fail("mg_set_maps: out of device memory while building episode templates");
-    } else {
+    if (dalloc(h, &kt.obs, PA * c.T * 3, true)) return 1;
+    if (dalloc(h, &kt.rewards, PA, true)) return 1;
+    if (dalloc(h, &kt.ep_rewards, PA, true)) return 1;
+    if (dalloc(h, &kt.term, PA, true)) return 1;
+    if (dalloc(h, &kt.trunc, PA, true)) return 1;
+    if (dalloc(h, &kt.success, PA, true)) return 1;
+    if (dalloc(h, &d_seeds, P, true)) return 1;
+    if (dalloc(h, &d_maps, P, true)) return 1;
+    if (big) {  // template builds must not touch the live grids of the environments
+      uint16_t* tg = nullptr;
+      if (dalloc(h, &tg, P * (size_t)HWp, true)) return 1;
+      kt.big_grid = tg;
+    }
+    {
       std::vector<int> iota((size_t)P);
       for (size_t i = 0; i < P; i++) iota[i] = (int)i;
-      hipError_t e1 = hipMemcpy(d_maps, iota.data(), P * 4, hipMemcpyHostToDevice);
+      HIPCHK(hipMemcpy(d_maps, iota.data(), P * 4, hipMemcpyHostToDevice));
       kt.reset_envs = nullptr;
+      kt.reset_count = nullptr;
       kt.reset_seeds = d_seeds;
       kt.reset_maps = d_maps;
       mg_launch_reset(kt, (unsigned)P, h->lds_bytes, h->big, 0);
       hipError_t e2 = hipGetLastError();
       hipError_t e3 = hipDeviceSynchronize();
-      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
-        rc = fail(std::string("mg_set_maps: template build failed: ") + hipGetErrorString(e3 != hipSuccess ? e3 : (e2 != hipSuccess ? e2 : e1)));
+      if (e2 != hipSuccess || e3 != hipSuccess)
+        return fail(std::string("mg_set_maps: template build failed: ") + hipGetErrorString(e3 != hipSuccess ? e3 : e2));
     }
-    for (void* q : tmp) (void)hipFree(q);
-    if (rc) return rc;
+    h->kt = kt;
+    h->d_iota = d_maps;
     k.t_chests = t_chests;
     k.t_agents = t_agents; k.t_asms = t_asms; k.t_astats = t_astats; k.t_atouched = t_atouched;
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
   k.map_max_steps = nullptr;  // (freed with the old pool)
+  if (!h->in_set_generated) h->generated = false;
   h->maps_set = true;
   h->needs_reset = true;
   if (k.map_stride >= num_maps) k.map_stride %= num_maps;
@@ -621,6 +630,159 @@ int mg_set_maps(mg_handle* h, const uint8_t* maps, int num_maps, int height, int
 
 int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const int32_t* heights, const int32_t* widths) {
   return mg_set_maps_impl(h, maps, num_maps, heights, widths);
+}
+
+// ---- device map generator ---------------------------------------------------------------------------------------
+static int mg_use_device(mg_handle* h);
+static int mg_refresh_impl(mg_handle* h, int force, hipStream_t st) {
+  MapGenArgs g = h->gen;
+  g.gen = ++h->gen.gen;
+  g.force = force;
+  HIPCHK(hipMemsetAsync(g.count, 0, sizeof(int), st));
+  if (!force) mg_launch_mark_maps(h->k.env, h->E, h->d_inuse, g.gen, st);
+  mg_launch_generate_maps(g, (unsigned)h->k.P, st);
+  HIPCHK(hipGetLastError());
+  // episode-start templates of the regenerated slots (blocks past the device-side count exit at once)
+  KArgs kt = h->kt;
+  kt.map_max_steps = h->k.map_max_steps;
+  kt.reset_envs = g.list;
+  kt.reset_maps = g.list;
+  kt.reset_count = g.count;
+  mg_launch_reset(kt, (unsigned)h->k.P, h->lds_bytes, h->big, st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int mg_set_generated_maps(mg_handle* h, int height, int width, int fill_code, int n_rooms, const int32_t* rooms,
+                          const int32_t* room_sym_begin, const int32_t* sym_code, const int32_t* sym_count, int num_maps,
+                          uint64_t seed) {
+  if (!h) return fail("mg_set_generated_maps: NULL handle");
+  if (!rooms || !room_sym_begin || (!sym_code && room_sym_begin[n_rooms > 0 ? n_rooms : 0] > 0) || n_rooms < 1)
+    return fail("mg_set_generated_maps: NULL argument or no rooms");
+  if (num_maps < 1 || height < 1 || width < 1) return fail("mg_set_generated_maps: bad dimensions");
+  if ((long long)height * width > MG_MAPGEN_MAX_CELLS)
+    return fail("mg_set_generated_maps: map larger than " + std::to_string(MG_MAPGEN_MAX_CELLS) + " cells (the generator builds a slot in LDS)");
+  const MgConfig& c = h->cfg;
+  auto code_ok = [&](int code) { return code >= 0 && (size_t)code < c.cells.size() && code < 256; };
+  if (!code_ok(fill_code) || (fill_code != 0 && c.cells[(size_t)fill_code].kind != MG_CELL_WALL))
+    return fail("mg_set_generated_maps: the border object must be empty or a wall type");
+  if (room_sym_begin[0] != 0) return fail("mg_set_generated_maps: room_sym_begin[0] must be 0");
+  std::vector<uint8_t> canon((size_t)height * width, (uint8_t)fill_code);
+  long long n_agents = 0;
+  for (int r = 0; r < n_rooms; r++) {
+    const int r0 = rooms[4 * r], c0 = rooms[4 * r + 1], rh = rooms[4 * r + 2], rw = rooms[4 * r + 3];
+    if (r0 < 0 || c0 < 0 || rh < 1 || rw < 1 || r0 + rh > height || c0 + rw > width)
+      return fail("mg_set_generated_maps: room " + std::to_string(r) + " lies outside the map");
+    for (int q = 0; q < r; q++) {
+      const int a0 = rooms[4 * q], b0 = rooms[4 * q + 1], ah = rooms[4 * q + 2], aw = rooms[4 * q + 3];
+      if (r0 < a0 + ah && a0 < r0 + rh && c0 < b0 + aw && b0 < c0 + rw)
+        return fail("mg_set_generated_maps: rooms " + std::to_string(q) + " and " + std::to_string(r) + " overlap");
+    }
+    if (room_sym_begin[r + 1] < room_sym_begin[r]) return fail("mg_set_generated_maps: room_sym_begin must not decrease");
+    long long total = 0;
+    for (int j = room_sym_begin[r]; j < room_sym_begin[r + 1]; j++) {
+      if (!code_ok(sym_code[j]) || sym_code[j] == 0) return fail("Unknown object type: cell code " + std::to_string(sym_code[j]) + " in the generator's symbol list");
+      if (sym_count[j] < 0) return fail("mg_set_generated_maps: negative symbol count");
+      total += sym_count[j];
+      if (c.cells[(size_t)sym_code[j]].kind == MG_CELL_AGENT) n_agents += sym_count[j];
+    }
+    if (total > (long long)rh * rw)
+      return fail("mg_set_generated_maps: room " + std::to_string(r) + " holds " + std::to_string(total) + " symbols but only " +
+                  std::to_string((long long)rh * rw) + " cells (halve the counts as the reference's builders do)");
+    // canonical layout: the room's symbols in row-major order (sizes the pool: assembler / chest slots per map)
+    for (int i = 0; i < rh * rw; i++) canon[(size_t)(r0 + i / rw) * width + c0 + i % rw] = 0;
+    int p = 0;
+    for (int j = room_sym_begin[r]; j < room_sym_begin[r + 1]; j++)
+      for (int q = 0; q < sym_count[j]; q++, p++) canon[(size_t)(r0 + p / rw) * width + c0 + p % rw] = (uint8_t)sym_code[j];
+  }
+  if (n_agents != c.A)
+    return fail("mg_set_generated_maps: the rooms hold " + std::to_string(n_agents) + " agents but the config says num_agents = " + std::to_string(c.A));
+  std::vector<uint8_t> pool((size_t)num_maps * canon.size());
+  for (int m = 0; m < num_maps; m++) memcpy(&pool[(size_t)m * canon.size()], canon.data(), canon.size());
+  h->in_set_generated = true;
+  h->generated = false;
+  int rc = mg_set_maps(h, pool.data(), num_maps, height, width);
+  h->in_set_generated = false;
+  if (rc) return rc;
+  h->maps_set = false;  // (until the first generation below has succeeded)
+  KArgs& k = h->k;
+  const int n_sym = room_sym_begin[n_rooms];
+  int *d_rooms, *d_begin, *d_code, *d_cnt, *d_list, *d_count;
+  uint32_t *d_state, *d_inuse;
+  uint8_t* d_bytes;
+  if (dalloc(h, &d_rooms, (size_t)n_rooms * 4, true) || dalloc(h, &d_begin, (size_t)n_rooms + 1, true) ||
+      dalloc(h, &d_code, (size_t)n_sym, true) || dalloc(h, &d_cnt, (size_t)n_sym, true) || dalloc(h, &d_list, (size_t)num_maps, true) ||
+      dalloc(h, &d_count, 1, true) || dalloc(h, &d_state, (size_t)num_maps, true) || dalloc(h, &d_inuse, (size_t)num_maps, true) ||
+      dalloc(h, &d_bytes, (size_t)num_maps * k.HW8, true))
+    return 1;
+  HIPCHK(hipMemcpy(d_rooms, rooms, (size_t)n_rooms * 16, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_begin, room_sym_begin, ((size_t)n_rooms + 1) * 4, hipMemcpyHostToDevice));
+  if (n_sym > 0) {
+    HIPCHK(hipMemcpy(d_code, sym_code, (size_t)n_sym * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_cnt, sym_count, (size_t)n_sym * 4, hipMemcpyHostToDevice));
+  }
+  MapGenArgs& g = h->gen;
+  memset(&g, 0, sizeof(g));
+  g.gdc = k.gdc;
+  g.height = height; g.width = width; g.fill_code = fill_code; g.n_rooms = n_rooms;
+  g.rooms = d_rooms; g.room_sym_begin = d_begin; g.sym_code = d_code; g.sym_count = d_cnt;
+  g.map_cells = const_cast<uint16_t*>(k.map_cells);
+  g.map_cells8 = const_cast<uint8_t*>(k.map_cells8);
+  g.map_bytes = d_bytes;
+  g.map_spawn = const_cast<int4*>(k.map_spawn);
+  g.map_asm = const_cast<int4*>(k.map_asm);
+  g.map_nasm = const_cast<int*>(k.map_nasm);
+  g.map_chest = const_cast<int4*>(k.map_chest);
+  g.map_nchest = const_cast<int*>(k.map_nchest);
+  g.map_objcount = const_cast<float*>(k.map_objcount);
+  g.HW = k.HW; g.HW8 = k.HW8; g.A = k.A; g.NW = k.NW; g.NAmax = k.NAmax; g.NCmax = k.NCmax; g.n_cells = k.n_cells;
+  g.slot_state = d_state; g.inuse = d_inuse; g.gen = 0;
+  g.list = d_list; g.count = d_count; g.status = k.status;
+  g.seed = seed;
+  h->d_inuse = d_inuse;
+  HIPCHK(mg_raise_lds_cap_mapgen(160 * 1024 - 4096));
+  if (mg_refresh_impl(h, 1, 0)) return 1;
+  HIPCHK(hipDeviceSynchronize());
+  h->generated = true;
+  h->maps_set = true;
+  h->needs_reset = true;
+  return 0;
+}
+
+int mg_refresh_maps(mg_handle* h, int force, void* stream) {
+  if (!h) return fail("mg_refresh_maps: NULL handle");
+  if (!h->maps_set || !h->generated) return fail("mg_refresh_maps: the pool was not made by mg_set_generated_maps");
+  if (mg_use_device(h)) return 1;
+  if (mg_refresh_impl(h, force ? 1 : 0, (hipStream_t)stream)) return 1;
+  if (force) h->needs_reset = true;  // maps changed under running episodes
+  return 0;
+}
+
+int mg_get_map(mg_handle* h, int map_id, uint8_t* out, void* stream) {
+  if (!h || !out) return fail("mg_get_map: NULL argument");
+  if (!h->maps_set || !h->generated) return fail("mg_get_map: the pool was not made by mg_set_generated_maps");
+  if (map_id < 0 || map_id >= h->k.P) return fail("mg_get_map: map id out of range");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(out, h->gen.map_bytes + (size_t)map_id * h->k.HW8, (size_t)h->gen.height * h->gen.width, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Inspection helpers read the object lists of a map from the host mirror; a generated pool lives on the device only.
+static int mg_sync_lists(mg_handle* h, uint32_t map_id) {
+  if (!h->generated) return 0;
+  const KArgs& k = h->k;
+  const size_t m = map_id;
+  int na = 0, nc = 0;
+  HIPCHK(hipMemcpy(&na, k.map_nasm + m, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&nc, k.map_nchest + m, 4, hipMemcpyDeviceToHost));
+  h->host_spawn[m].resize((size_t)k.A);
+  h->host_asm[m].resize((size_t)na);
+  h->host_chest[m].resize((size_t)nc);
+  HIPCHK(hipMemcpy(h->host_spawn[m].data(), k.map_spawn + m * k.A, (size_t)k.A * sizeof(int4), hipMemcpyDeviceToHost));
+  if (na) HIPCHK(hipMemcpy(h->host_asm[m].data(), k.map_asm + m * k.NAmax, (size_t)na * sizeof(int4), hipMemcpyDeviceToHost));
+  if (nc) HIPCHK(hipMemcpy(h->host_chest[m].data(), k.map_chest + m * k.NCmax, (size_t)nc * sizeof(int4), hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int mg_set_map_max_steps(mg_handle* h, const int32_t* max_steps) {
@@ -923,6 +1085,7 @@ int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream) {
   DEnv d;
   HIPCHK(hipMemcpy(ag.data(), k.agents + (size_t)env * k.A, ag.size() * sizeof(DAgent), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  if (mg_sync_lists(h, d.map_id)) return 1;
   int R = k.R, stride = 9 + 2 * R;
   for (int i = 0; i < k.A; i++) {
     const DAgent& a = ag[(size_t)i];
@@ -959,6 +1122,7 @@ int mg_chest_state(mg_handle* h, int env, int32_t* out, int max_chests, int32_t*
   const KArgs& k = h->k;
   DEnv d;
   HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  if (mg_sync_lists(h, d.map_id)) return 1;
   const auto& lst = h->host_chest[(size_t)d.map_id];
   *n_chests = (int32_t)lst.size();
   if (!out || lst.empty()) return 0;
@@ -982,6 +1146,7 @@ int mg_num_assemblers(mg_handle* h, int env) {
   if (!h || env < 0 || env >= h->E) return -1;
   DEnv d;
   if (hipMemcpy(&d, h->k.env + env, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (mg_sync_lists(h, d.map_id)) return -1;
   return (int)h->host_asm[(size_t)d.map_id].size();
 }
 
@@ -993,6 +1158,7 @@ int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream) {
   const KArgs& k = h->k;
   DEnv d;
   HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  if (mg_sync_lists(h, d.map_id)) return 1;
   const auto& lst = h->host_asm[(size_t)d.map_id];
   std::vector<DAsm> as((size_t)k.NAmax);
   HIPCHK(hipMemcpy(as.data(), k.asms + (size_t)env * k.NAmax, as.size() * sizeof(DAsm), hipMemcpyDeviceToHost));

@@ -92,6 +92,7 @@ struct KArgs {
   const int* reset_envs;  // reset kernel only
   const uint32_t* reset_seeds;
   const int* reset_maps;
+  const int* reset_count;  // or null: blocks at or past *reset_count leave at once (device-side list lengths)
 };
 
 struct Lds {

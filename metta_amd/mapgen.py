@@ -12,6 +12,10 @@ reference's builders is not required -- only the same distributi
   (reference: `PY/mapgen/mapgen.py:259-292`, `PY/mapgen/scenes/random.py:19-69`).
 * `AsciiMapBuilder`   — literal maps (reference: `PY/map_builder/ascii.py`).
 
+`RandomMapBuilder` and `ArenaMapBuilder` can also describe themselves as a `DeviceMapSpec` (`device_spec()`): border
+object, rooms, symbols per room -- what the library's device generator (`mg_set_generated_maps`, `mg_refresh_maps`,
+csrc/k_mapgen.hip) needs to draw maps of the same distribution in HBM and keep the pool fresh without the host.
+
 Every builder returns a `numpy` array of cell *names* (dtype `<U50`), the same representation as the
 reference's `GameMap.grid`, so `grid.tolist()` is the `list[list[str]]` the reference constructor takes.
 """
@@ -39,6 +43,63 @@ def _draw_border(grid: np.ndarray, width: int, name: str) -> None:
     grid[-width:, :] = name
     grid[:, :width] = name
     grid[:, -width:] = name
+
+
+@dataclass
+class DeviceMapSpec:
+    """A border object, disjoint rooms, and the multiset of symbols shuffled over each room's cells."""
+
+    height: int
+    width: int
+    fill: str  # cell name outside the rooms ("empty" or a wall type)
+    rooms: list  # [(r0, c0, h, w)]
+    room_symbols: list  # per room: [(cell name, count)]
+
+    def encode(self, compiled) -> dict:
+        """Cell names -> the codes `CompiledGame.encode_map` uses; flat int32 arrays for the C-ABI."""
+
+        def code(name: str) -> int:
+            if name == "empty":
+                return 0
+            if name not in compiled.cell_code:
+                raise RuntimeError(f"Unknown object type: {name}")
+            return int(compiled.cell_code[name])
+
+        begin, codes, counts = [0], [], []
+        for syms in self.room_symbols:
+            for name, n in syms:
+                if n > 0:
+                    codes.append(code(name))
+                    counts.append(int(n))
+            begin.append(len(codes))
+        return {
+            "height": int(self.height),
+            "width": int(self.width),
+            "fill_code": code(self.fill),
+            "rooms": np.ascontiguousarray(np.asarray(self.rooms, dtype=np.int32).reshape(-1, 4)),
+            "room_sym_begin": np.asarray(begin, dtype=np.int32),
+            "sym_code": np.asarray(codes if codes else [0], dtype=np.int32),
+            "sym_count": np.asarray(counts if counts else [0], dtype=np.int32),
+        }
+
+
+@dataclass
+class GeneratedMaps:
+    """Pass as `maps` to `MettaGridBatch` / the vecenv: a pool of `num_maps` slots drawn on the device from `spec`."""
+
+    spec: DeviceMapSpec
+    num_maps: int
+    seed: int = 0
+
+
+def _counted(symbols: list) -> list:
+    out: list = []
+    for s in symbols:
+        if out and out[-1][0] == s:
+            out[-1][1] += 1
+        else:
+            out.append([s, 1])
+    return [(a, b) for a, b in out]
 
 
 @dataclass
@@ -79,6 +140,24 @@ class RandomMapBuilder:
         bw = self.border_width
         grid[bw : bw + ih, bw : bw + iw] = arr[:area].reshape(ih, iw)
         return grid
+
+    def device_spec(self) -> DeviceMapSpec:
+        """The same distribution for the device generator: one room inside the border, counts halved until they fit
+        (random_map.py:62-71)."""
+        bw = max(0, self.border_width)
+        ih = max(0, self.height - 2 * bw)
+        iw = max(0, self.width - 2 * bw)
+        agents = _agent_symbols(self.agents)
+        objects = dict(self.objects)
+        total = sum(objects.values()) + len(agents)
+        while total > ih * iw:
+            if all(c <= 1 for c in objects.values()) and len(agents) <= 1:
+                break
+            for k in objects:
+                objects[k] = max(1, objects[k] // 2)
+            total = sum(objects.values()) + len(agents)
+        syms = [(k, n) for k, n in objects.items()] + _counted(agents)
+        return DeviceMapSpec(self.height, self.width, self.border_object if bw > 0 else "empty", [(bw, bw, ih, iw)], [syms])
 
 
 def _random_scene(grid: np.ndarray, objects: dict, agents: Union[int, dict], rng: np.random.Generator) -> None:
@@ -134,6 +213,23 @@ class ArenaMapBuilder:
                 grid[r0 : r0 + self.height, c0 : c0 + self.width] = room
                 k += 1
         return grid
+
+    def device_spec(self) -> DeviceMapSpec:
+        """One room per instance, the Random scene's symbols in each (objects capped to the room, random.py:43-47)."""
+        n = self.num_agents // self.agents_per_instance
+        rows = int(np.ceil(np.sqrt(n)))
+        cols = int(np.ceil(n / rows))
+        ibw, bw = self.instance_border_width, self.border_width
+        ih = self.height * rows + (rows - 1) * ibw
+        iw = self.width * cols + (cols - 1) * ibw
+        if sum(self.objects.values()) + self.agents_per_instance > self.height * self.width:
+            raise ValueError("device generator: the room's objects and agents must fit the room")
+        rooms, syms = [], []
+        for k in range(n):
+            r, c = divmod(k, cols)
+            rooms.append((bw + r * (self.height + ibw), bw + c * (self.width + ibw), self.height, self.width))
+            syms.append([(o, cnt) for o, cnt in self.objects.items()] + [("agent.agent", self.agents_per_instance)])
+        return DeviceMapSpec(ih + 2 * bw, iw + 2 * bw, "wall", rooms, syms)
 
 
 DEFAULT_CHAR_TO_NAME = {

@@ -89,10 +89,29 @@ class MettaGridDeviceVecEnv:
         early_reset: bool = True,
         map_seed: int = 0,
         init_obs_passes: int = 2,
+        device_maps: bool = False,
+        map_refresh_every: Optional[int] = None,
     ):
         self.cfg = cfg
         self.policy_env_info = PolicyEnvInterface.from_mg_cfg(cfg)
         game = cfg.game
+        # device_maps: the pool is drawn and kept fresh on the GPU (csrc/k_mapgen.hip) -- 2E slots, every environment
+        # alternates between two of them and the idle one is redrawn every `map_refresh_every` steps (default
+        # max_steps / 2), so that each episode plays a new map like the reference's per-episode map_builder.build()
+        # (simulator.py:264-267) with no host work.  (Per-group statistics of an episode reported late are grouped by
+        # the slot's current agents: exact when all agents share a group or `stats_every` = 1.)
+        self.device_maps = bool(device_maps)
+        self._map_refresh_every = 0
+        if self.device_maps:
+            from .mapgen import GeneratedMaps
+
+            if maps is not None:
+                raise ValueError("device_maps=True draws the maps itself: do not pass `maps`")
+            if not hasattr(game.map_builder, "device_spec"):
+                raise ValueError(f"{type(game.map_builder).__name__} has no device generator (random builders only)")
+            maps = GeneratedMaps(game.map_builder.device_spec(), 2 * int(num_envs), map_seed)
+            ms = int(game.max_steps)
+            self._map_refresh_every = int(map_refresh_every) if map_refresh_every else max(1, ms // 2 if ms > 0 else 256)
         if maps is None:
             rng = np.random.default_rng(map_seed)
             maps = [game.map_builder.build(rng) for _ in range(num_maps)]
@@ -100,7 +119,7 @@ class MettaGridDeviceVecEnv:
         # 1 = a bare `Simulation` without shared buffers
         self.compiled = compile_game(cfg, init_obs_passes=init_obs_passes)
         self.batch = MettaGridBatch(cfg, num_envs, maps, device=device, compiled=self.compiled)
-        self.batch.set_auto_reset(True, 1)
+        self.batch.set_auto_reset(True, int(num_envs) if self.device_maps else 1)
         self.num_environments = int(num_envs)
         self.agents_per_env = game.num_agents
         self.num_agents = self.num_environments * self.agents_per_env
@@ -217,6 +236,8 @@ class MettaGridDeviceVecEnv:
             actions = actions.to(torch.int32)  # the vecenv casts like pufferlib's send (vector.py), the env itself is strict
         b.step(actions.reshape(-1))
         self._steps += 1
+        if self._map_refresh_every and self._steps % self._map_refresh_every == 0:
+            b.refresh_maps()  # stream-ordered, no host sync
         if self.stats_every == 0:
             self._poll_status()
         elif self.stats_every == 1:

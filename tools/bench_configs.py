@@ -3,6 +3,7 @@
 
   python3 tools/bench_configs.py navigation   # 8192 envs x 4 agents, 64 maps of mixed sizes (60..120)^2
   python3 tools/bench_configs.py combat [steps] [envs]  # 64 (default) envs x 1024 agents on 256 x 256 maps (grid tiles in HBM)
+  python3 tools/bench_configs.py mapgen       # 4096 arena envs, 8192 device-generated slots: cost of one pool refresh
   python3 tools/bench_configs.py rollout      # configs[4] on one GPU: 4096 arena envs x 24 agents + LSTM policy (bf16)
 """
 import json
@@ -25,6 +26,8 @@ def main():
     rs = np.random.RandomState(0)
     if which == "rollout":
         return rollout_bench(steps)
+    if which == "mapgen":
+        return mapgen_bench()
     if which == "navigation":
         A, E = 4, 8192
         cfg = make_navigation(A)
@@ -55,6 +58,54 @@ def main():
     ms = b.profile_read(4096)
     print(json.dumps({"workload": which, "envs": E, "agents_per_env": A, "steps": steps, "ms_per_step": dt / steps * 1e3,
                       "kernel_ms_mean": float(ms.mean()), "agent_steps_per_s": E * A * steps / dt}))
+    b.close()
+
+
+def mapgen_bench():
+    from metta_amd.builder import make_arena
+    from metta_amd.mapgen import GeneratedMaps
+
+    cfg = make_arena(24)
+    E = 4096
+    t0 = time.perf_counter()
+    b = MettaGridBatch(cfg, E, GeneratedMaps(cfg.game.map_builder.device_spec(), 2 * E, 0), device=0, seeds=list(range(E)))
+    torch.cuda.synchronize()
+    t_create = time.perf_counter() - t0
+    b.set_auto_reset(True, E)
+    table = torch.randint(0, 5, (16, E * 24), device="cuda", dtype=torch.int32)
+    acts = table[0]
+    out = {"workload": "device map pool, arena 62x62, 4096 envs, 8192 slots", "create_s": t_create}
+    for name, force in (("refresh_all_8192_slots_ms", True), ("refresh_nothing_to_do_ms", False)):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            b.refresh_maps(force=force)
+        ev1.record()
+        torch.cuda.synchronize()
+        out[name] = ev0.elapsed_time(ev1) / 5
+    b.reset(seeds=list(range(E)))
+    # steady state: short episodes so that slots turn over; a refresh every 50 steps
+    b.end_episode()
+    b.step(acts)
+    b.step(acts)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    b.refresh_maps()
+    ev1.record()
+    torch.cuda.synchronize()
+    out["refresh_4096_used_idle_slots_ms"] = ev0.elapsed_time(ev1)
+    for t in range(20):
+        b.step(table[t % 16])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(1000):
+        b.step(table[t % 16])
+        if t % 100 == 99:
+            b.refresh_maps()
+    torch.cuda.synchronize()
+    out["ms_per_step_with_a_refresh_every_100_steps"] = (time.perf_counter() - t0)  # 1000 steps: s == ms per step
+    b.check_errors()
+    print(json.dumps(out))
     b.close()
 
 
