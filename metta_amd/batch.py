@@ -86,6 +86,8 @@ class MettaGridBatch:
         seeds: Optional[Sequence[int]] = None,
         map_ids: Optional[Sequence[int]] = None,
         compiled: Optional[CompiledGame] = None,
+        config_slots: int = 0,
+        config_headroom_words: int = -1,
     ):
         import torch
 
@@ -102,6 +104,10 @@ class MettaGridBatch:
         self._h = ct.c_void_p()
         native.check(self.L.mg_create(_p(blob, ct.c_int32), blob.size, self.num_envs, self.device_index, ct.byref(self._h)))
         self._owner = _HandleOwner(self.L, self._h)
+        self.config_slots = int(config_slots)
+        self._init_obs_passes = int(init_obs_passes)  # (tasks are compiled like the handle's own configuration)
+        if self.config_slots > 0:  # per-slot configurations (curriculum tasks): before the pool, which is sized for them
+            native.check(self.L.mg_set_config_slots(self._h, self.config_slots, int(config_headroom_words)))
         self.set_maps(maps)
         b = native.MgBuffers()
         native.check(self.L.mg_get_buffers(self._h, ct.byref(b)))
@@ -187,6 +193,24 @@ class MettaGridBatch:
         out = np.zeros((self.map_height, self.map_width), np.uint8)
         native.check(self.L.mg_get_map(self._h, int(map_id), _p(out, ct.c_uint8), self._stream()))
         return out
+
+    def write_config_slot(self, slot: int, cfg) -> None:
+        """Compile `cfg` (a MettaGridConfig, or a CompiledGame) into configuration slot `slot`: the device side of
+        `CurriculumEnv`'s `env.set_mg_config(task.get_env_cfg())` (curriculum_env.py:111-126).  Raises RuntimeError when
+        the task differs from this handle's configuration in what sizes buffers or observations."""
+        comp = cfg if isinstance(cfg, CompiledGame) else compile_game(cfg, init_obs_passes=self._init_obs_passes)
+        if comp.agent_slot_names != self.compiled.agent_slot_names or comp.game_slot_names != self.compiled.game_slot_names:
+            raise RuntimeError("mg_write_config_slot: the task's configuration differs from the handle's in the statistics layout")
+        blob = np.ascontiguousarray(comp.blob, dtype=np.int32)
+        native.check(self.L.mg_write_config_slot(self._h, int(slot), _p(blob, ct.c_int32), blob.size, self._stream()))
+
+    def assign_map_configs(self, map_ids: Sequence[int], cfg_slots: Sequence[int]) -> None:
+        """Map slot map_ids[i] plays configuration slot cfg_slots[i] from its next episode start on."""
+        m = np.ascontiguousarray(map_ids, dtype=np.int32)
+        c = np.ascontiguousarray(cfg_slots, dtype=np.int32)
+        if m.shape != c.shape or m.ndim != 1:
+            raise RuntimeError("map_ids and cfg_slots must be 1-D and of equal length")
+        native.check(self.L.mg_assign_map_configs(self._h, len(m), _p(m, ct.c_int32), _p(c, ct.c_int32), self._stream()))
 
     def set_map_max_steps(self, max_steps: Optional[Sequence[int]]) -> None:
         """Episode length per map of the pool (0 = the configuration's `max_steps`); None clears it.  The reference's

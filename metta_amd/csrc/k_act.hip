@@ -139,17 +139,21 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
     l.ag = a.agents + (size_t)e * a.A;
     l.ch = a.chests + (size_t)e * a.NCmax;
   }
-  if (DCL) {
+  const bool slots = a.map_cfg != nullptr;  // per-slot configurations: the stream is known only after the env words
+  if (DCL && !slots)
     for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
-    a.dc = l.dc;
-  }
   DEnv env = a.env[e];
-  const int* dc = a.dc;
   const int A = a.A;
 
   const bool do_reset = a.auto_reset && env.done;  // block-uniform
   if (do_reset) mg_restart_env(a, e, env, tid, nt);
   mg_use_map(a, env.map_id);
+  if (DCL) {
+    if (slots)
+      for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.gdc)[i];
+    a.dc = l.dc;
+  }
+  const int* dc = a.dc;
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   if (!BIG) {
     const uint4* src = (const uint4*)(a.agents + (size_t)e * A);

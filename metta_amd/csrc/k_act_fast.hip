@@ -19,7 +19,6 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
   __shared__ uint32_t mtnext[624];
   const int lane = threadIdx.x, e = blockIdx.x + a.env_base;
   const int A = a.A;
-  const int* dc = a.dc;
   const bool active = lane < A;
   const size_t g = (size_t)e * A + (active ? lane : 0);
   DAgent* rec = a.agents + g;
@@ -44,6 +43,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
     load_agent();
   }
   mg_use_map(a, env.map_id);
+  const int* dc = a.dc;
   const int H = a.H, W = a.W;
   int r = (int)(f0.x & 0xFFFF), c = (int)(f0.x >> 16);
   int frozen = (int)(int16_t)(f0.z & 0xFFFF);

@@ -420,7 +420,7 @@ __device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& 
 // together need several times the registers any one of them does).
 template <bool DCL>
 __device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id,
-                                               int max_steps) {
+                                               int max_steps, int cfg_off) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __attribute__((address_space(4))) KArgs* ka =
       (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -433,7 +433,8 @@ __device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* 
   l.gmap = a.map_cells8 + (size_t)map_id * a.HW8;
   l.as = a.asms + (size_t)e * a.NAmax;                             // used in place (HBM)
   l.ainfo = (int4*)(a.map_asm + (size_t)map_id * a.NAmax);         // read only
-  if (DCL) a.dc = l.dc;
+  a.gdc += cfg_off;  // per-slot configurations (0 without)
+  a.dc = DCL ? l.dc : a.gdc;
   a.H = H;
   a.W = W;
   a.max_steps = max_steps;
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   const int tid = threadIdx.x, nt = MG_FUSED_THREADS;
   const int lane = tid & 63, wave = tid >> 6;
   DEnv env;
-  int H, W, act = 0, NW_, actor = 0, max_steps;
+  int H, W, act = 0, NW_, actor = 0, max_steps, cfg_off;
   uint32_t mt_raw = 0;
 
   // ---- P0: stage -----------------------------------------------------------------------------------------------
@@ -466,7 +467,8 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
       if (tid < n1) v1 = s1[tid];
       if (tid + nt < n1) v2 = s1[tid + nt];
     }
-    if (DCL) {
+    const bool slots = a.map_cfg != nullptr;  // per-slot configurations: the stream is known only after the env words
+    if (DCL && !slots) {
       const uint4* __restrict__ s0 = (const uint4*)a.gdc;
       uint4* d0 = (uint4*)l.dc;
       for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
@@ -475,6 +477,12 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
     const bool do_reset = a.auto_reset && env.done;  // block-uniform
     if (do_reset) mg_restart_env(a, e, env, tid, nt);
     mg_use_map(a, env.map_id);
+    cfg_off = (int)(a.gdc - a0.gdc);
+    if (DCL && slots) {
+      const uint4* __restrict__ s0 = (const uint4*)a.gdc;
+      uint4* d0 = (uint4*)l.dc;
+      for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];
+    }
     H = a.H;
     W = a.W;
     max_steps = a.max_steps;
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   if (wave == actor) {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
     uint32_t w = 0;
     {
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(2);
     const int n_uses = l.flags[3];
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     __syncthreads();  // (the use scratch becomes the token lists)
     mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
     __syncthreads();
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs a;
     Lds l;
-    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps);
+    mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
     if (!(a.diag & 16)) mg_encode_all<uint8_t, false, true>(a, l, e, env.step, l.exec, true, tid, nt);
     __syncthreads();
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
   {
     KArgs b;
     Lds l;
-    mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id, max_steps);
+    mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + b.env_base;
     if (wave == 0) {
       mg_fused_token_stats(b, l, lane);

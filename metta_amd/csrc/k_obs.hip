@@ -19,13 +19,17 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
     l.ag = a.agents + (size_t)e * a.A;
     l.ch = a.chests + (size_t)e * a.NCmax;
   }
-  if (DCL) {
+  const bool slots = a.map_cfg != nullptr;  // per-slot configurations: the stream is known only after the env words
+  if (DCL && !slots)
     for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
-    a.dc = l.dc;
-  }
   MG_STAMP(0);
   DEnv env = a.env[e];
   mg_use_map(a, env.map_id);
+  if (DCL) {
+    if (slots)
+      for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.gdc)[i];
+    a.dc = l.dc;
+  }
   mg_load_grid(a, l, (int)env.map_id, tid, nt);
   {
     if (!BIG) {
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
     b = *ka;
   }
 #endif
-  b.dc = a.dc; b.H = a.H; b.W = a.W;
+  b.dc = a.dc; b.gdc = a.gdc; b.H = a.H; b.W = a.W; b.max_steps = a.max_steps;
   if (tid == 0) {
     mg_token_stats(b, l, 1);
     float* gs_ = b.gstats + (size_t)e * b.SG;

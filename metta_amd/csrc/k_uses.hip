@@ -22,6 +22,7 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   const int count = (int)(mode >> 8);
   Lds l;
   mg_carve_uses<true>(smem, &l, a.A, a.NAmax, a.SG, DCL ? a.dc_words : 0);
+  mg_use_map(a, map_id);  // (per-slot configurations: a.gdc becomes the slot's stream)
   MG_STAMP(8);
   // every staging load is independent of the others: issue them together, one barrier
   {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
     const int4* __restrict__ s4 = a.map_asm + (size_t)map_id * a.NAmax;  // read by every use: keep it off the chain
     for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = s4[i];
     if (DCL) {
-      const uint4* __restrict__ s0 = (const uint4*)a.dc;
+      const uint4* __restrict__ s0 = (const uint4*)a.gdc;
       uint4* d0 = (uint4*)l.dc;
       for (int i = tid; i < (a.dc_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
     }
@@ -49,7 +50,6 @@ __global__ __launch_bounds__(MG_USES_THREADS) void mg_uses_kernel(KArgs a) {
   }
   if (DCL) a.dc = l.dc;
   Ctx cx;
-  mg_use_map(a, map_id);
   mg_make_ctx(a, l, cx, e, (int)map_id, step);
   cx.grid = nullptr;
   cx.asm_info = l.ainfo;

@@ -43,6 +43,7 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   return;
 #endif
   if (threadIdx.x != 0) return;
+  mg_use_map(a, a.env[e].map_id);  // (per-slot configurations: the environment's own stream)
   DAgent* ag = (DAgent*)smem;
   uint32_t* dirty = (uint32_t*)(smem + mg_align16(sizeof(DAgent)));
   *ag = a.agents[(size_t)e * a.A + agent];
@@ -155,6 +156,14 @@ struct mg_handle {
   MapGenArgs gen;
   uint32_t* d_inuse = nullptr;
   bool in_set_generated = false;
+  // per-slot configurations (mg_set_config_slots): K streams of dc_stride words; map slot m plays stream map_cfg[m]
+  int n_cfg_slots = 0;
+  int base_dc_words = 0, base_obs_words = 0;
+  std::vector<int32_t> base_dcfg;
+  std::vector<int32_t> host_map_cfg;  // [P]
+  int* d_map_cfg = nullptr;           // [P] (lives with the pool)
+  int* d_tlist = nullptr;             // [P] staging for template rebuild lists (lives with the pool)
+  int ts[4] = {0, 0, 0, 0};           // token-list strides TSW, TSA, TSS, TSC the pool was sized for
 };
 
 // ---- static scratch of the allocation-free step (mg_step_noalloc) ---------------------------------------------
@@ -183,6 +192,51 @@ static int mg_scratch_init(int device) {
   if (!p) return fail("mg_create: hipGetSymbolAddress(mg_scratch) returned NULL");
   g_scratch_ptr[device] = (unsigned char*)p;
   return 0;
+}
+
+static bool mg_has_damage(const MgConfig& c) {
+  for (const auto& g : c.groups)
+    if (!g.damage_threshold.empty() && !g.damage_resources.empty()) return true;
+  return false;
+}
+
+static int mg_check_supported(const MgConfig& c, const char* who) {
+  if (c.R > MGD_MAX_R) return fail(std::string(who) + ": more than 16 resources are not supported on the device path yet");
+  if (c.A > 8191) return fail(std::string(who) + ": too many agents per environment");
+  for (const auto& a : c.assemblers)
+    for (const auto& p : a.protocols)
+      if (p.vibes.size() > 8) return fail(std::string(who) + ": protocols with more than 8 vibes are not supported");
+  return 0;
+}
+
+// fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
+static bool mg_fast_eligible(const MgConfig& c) {
+  bool ok = c.A <= 64 && c.regen_interval == 0 && !mg_has_damage(c) && c.chests.empty();
+  for (int v : c.vibe_handler) ok = ok && v == 0;
+  for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
+  return ok;
+}
+
+static bool mg_has_modifiers(const MgConfig& c) {
+  for (const auto& g : c.groups)
+    for (const auto& lim : g.inv.limits)
+      if (!lim.modifiers.empty()) return true;
+  return false;
+}
+
+// token-list strides: the most tokens an object of each kind can show (wall.hpp:26-38, agent.cpp:187-213,
+// assembler.hpp:528-578, chest.hpp:124-146), rounded to 4 (lists are read 4 tokens = 8 bytes at a time)
+static void mg_token_strides(const MgConfig& c, int ts[4]) {
+  int TSW = 1, TSA = 1, TSS = 1, TSC = 1;
+  for (const auto& wl : c.walls) TSW = std::max(TSW, (int)wl.tags.size() + 1);
+  for (const auto& g : c.groups) TSA = std::max(TSA, 3 + c.R * c.n_inv_tokens + (int)g.tags.size());
+  for (const auto& a : c.assemblers) {
+    int io = 0;
+    for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
+    TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
+  }
+  for (const auto& ch : c.chests) TSC = std::max(TSC, 1 + c.R * c.n_inv_tokens + (int)ch.tags.size());
+  ts[0] = TSW; ts[1] = TSA; ts[2] = TSS; ts[3] = TSC;
 }
 
 template <class T>
@@ -219,15 +273,8 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
     return fail(std::string("mg_create: ") + ex.what());
   }
   const MgConfig& c = h->cfg;
-  if (c.R > MGD_MAX_R) return fail("mg_create: more than 16 resources are not supported on the device path yet");
-  bool has_damage = false;
-  for (const auto& g : c.groups)
-    if (!g.damage_threshold.empty() && !g.damage_resources.empty()) has_damage = true;
-  if (c.A > 8191) return fail("mg_create: too many agents per environment");
-  for (const auto& a : c.assemblers) {
-    for (const auto& p : a.protocols)
-      if (p.vibes.size() > 8) return fail("mg_create: protocols with more than 8 vibes are not supported");
-  }
+  if (mg_check_supported(c, "mg_create")) return 1;
+  const bool has_damage = mg_has_damage(c);
   if (device_id >= 0) {
     HIPCHK(hipSetDevice(device_id));
     h->device = device_id;
@@ -250,10 +297,7 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   k.max_steps = k.max_steps_cfg = c.max_steps;
   k.map_max_steps = nullptr;
   {
-    // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
-    bool ok = c.A <= 64 && c.regen_interval == 0 && !has_damage && c.chests.empty();
-    for (int v : c.vibe_handler) ok = ok && v == 0;
-    for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
+    bool ok = mg_fast_eligible(c);
     const char* dg = getenv("MG_DIAG");
     k.diag = dg ? atoi(dg) : 0;
     const char* force = getenv("MG_FORCE_GENERAL");
@@ -269,6 +313,11 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   k.gdc = d_dc;
   k.dc_words = (int)dcfg.size();
   k.dc_obs_words = dcfg[DC_OBS_WORDS];
+  k.dc_stride = k.dc_words;
+  k.map_cfg = nullptr;
+  h->base_dcfg = dcfg;
+  h->base_dc_words = k.dc_words;
+  h->base_obs_words = k.dc_obs_words;
   size_t N = (size_t)num_envs * c.A;
   if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
@@ -424,18 +473,15 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   // LDS budget
   // token-list strides: the most tokens an object of each kind can show (wall.hpp:26-38, agent.cpp:187-213,
   // assembler.hpp:528-578)
-  int TSW = 1, TSA = 1, TSS = 1;
-  for (const auto& wl : c.walls) TSW = std::max(TSW, (int)wl.tags.size() + 1);
-  for (const auto& g : c.groups) TSA = std::max(TSA, 3 + c.R * c.n_inv_tokens + (int)g.tags.size());
-  for (const auto& a : c.assemblers) {
-    int io = 0;
-    for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
-    TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
+  int ts_[4];
+  mg_token_strides(c, ts_);
+  if (h->n_cfg_slots > 0) {  // room for tasks that show a few more tokens per object than the base configuration
+    ts_[1] += 4; ts_[2] += 4; ts_[3] += 4;
   }
-  int TSC = 1;
-  for (const auto& ch : c.chests) TSC = std::max(TSC, 1 + c.R * c.n_inv_tokens + (int)ch.tags.size());  // chest.hpp:124-146
+  int TSW = ts_[0], TSA = ts_[1], TSS = ts_[2], TSC = ts_[3];
   if (TSW > 255 || TSA > 255 || TSS > 255 || TSC > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
   TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3; TSC = (TSC + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time
+  h->ts[0] = TSW; h->ts[1] = TSA; h->ts[2] = TSS; h->ts[3] = TSC;
   const int NOBJ = (int)c.walls.size() + c.A + NAmax + NCmax;
   const int HEAP = (int)c.walls.size() * TSW + c.A * TSA + NAmax * TSS + NCmax * TSC;
   const int NP = c.obs_h * c.obs_w;
@@ -537,9 +583,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         k.map_cells8 = d8;
       }
       if (h->fused) {
-        h->no_modifiers = true;
-        for (const auto& g : c.groups)
-          for (const auto& lim : g.inv.limits) h->no_modifiers = h->no_modifiers && lim.modifiers.empty();
+        h->no_modifiers = !mg_has_modifiers(c);
         HIPCHK(mg_raise_lds_cap_fused((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
       }
@@ -556,6 +600,15 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     HIPCHK(mg_raise_lds_cap_uses(cap));
     HIPCHK(mg_raise_lds_cap_obs(cap));
     HIPCHK(mg_raise_lds_cap_reset(cap));
+  }
+  // per-slot configurations: every map slot starts on configuration slot 0
+  k.map_cfg = nullptr;
+  h->d_map_cfg = nullptr;
+  h->host_map_cfg.assign((size_t)num_maps, 0);
+  if (dalloc(h, &h->d_tlist, (size_t)num_maps, true)) return 1;
+  if (h->n_cfg_slots > 0) {
+    if (dalloc(h, &h->d_map_cfg, (size_t)num_maps, true)) return 1;
+    k.map_cfg = h->d_map_cfg;
   }
   // ---- episode-start templates: run the reset kernel once per map into template buffers ------------------
   {
@@ -645,6 +698,7 @@ static int mg_refresh_impl(mg_handle* h, int force, hipStream_t st) {
   // episode-start templates of the regenerated slots (blocks past the device-side count exit at once)
   KArgs kt = h->kt;
   kt.map_max_steps = h->k.map_max_steps;
+  kt.map_cfg = h->k.map_cfg;
   kt.reset_envs = g.list;
   kt.reset_maps = g.list;
   kt.reset_count = g.count;
@@ -783,6 +837,129 @@ static int mg_sync_lists(mg_handle* h, uint32_t map_id) {
   if (na) HIPCHK(hipMemcpy(h->host_asm[m].data(), k.map_asm + m * k.NAmax, (size_t)na * sizeof(int4), hipMemcpyDeviceToHost));
   if (nc) HIPCHK(hipMemcpy(h->host_chest[m].data(), k.map_chest + m * k.NCmax, (size_t)nc * sizeof(int4), hipMemcpyDeviceToHost));
   return 0;
+}
+
+// ---- per-slot configurations (curriculum tasks) -----------------------------------------------------------------
+int mg_set_config_slots(mg_handle* h, int num_slots, int headroom_words) {
+  if (!h) return fail("mg_set_config_slots: NULL handle");
+  if (h->maps_set) return fail("mg_set_config_slots: call before mg_set_maps (the pool is sized for the slots)");
+  if (num_slots < 1 || num_slots > (1 << 20)) return fail("mg_set_config_slots: bad slot count");
+  if (headroom_words < 0) headroom_words = h->base_dc_words / 4 + 64;
+  HIPCHK(hipSetDevice(h->device));
+  KArgs& k = h->k;
+  const int stride = (int)((h->base_dc_words + headroom_words + 3) & ~3);
+  const int obs_words = (int)std::min<long long>(stride, ((long long)h->base_obs_words + headroom_words + 3) & ~3LL);
+  int* d = nullptr;
+  if (dalloc(h, &d, (size_t)num_slots * stride)) return 1;
+  std::vector<int32_t> all((size_t)num_slots * stride, 0);
+  for (int s = 0; s < num_slots; s++) memcpy(&all[(size_t)s * stride], h->base_dcfg.data(), h->base_dcfg.size() * 4);
+  HIPCHK(hipMemcpy(d, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  k.dc = d;
+  k.gdc = d;
+  k.dc_stride = stride;
+  k.dc_words = stride;          // LDS staging copies the slot's whole stride / the largest prefix
+  k.dc_obs_words = obs_words;
+  h->n_cfg_slots = num_slots;
+  return 0;
+}
+
+static int mg_rebuild_templates(mg_handle* h, const std::vector<int>& maps, hipStream_t st) {
+  if (maps.empty()) return 0;
+  HIPCHK(hipMemcpyAsync(h->d_tlist, maps.data(), maps.size() * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // (the list is a stack vector of the caller)
+  KArgs kt = h->kt;
+  kt.map_max_steps = h->k.map_max_steps;
+  kt.map_cfg = h->k.map_cfg;
+  kt.reset_envs = h->d_tlist;
+  kt.reset_maps = h->d_tlist;
+  kt.reset_count = nullptr;
+  mg_launch_reset(kt, (unsigned)maps.size(), h->lds_bytes, h->big, st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t cfg_words, void* stream) {
+  if (!h || !cfg_blob) return fail("mg_write_config_slot: NULL argument");
+  if (h->n_cfg_slots < 1) return fail("mg_write_config_slot: call mg_set_config_slots first");
+  if (slot < 0 || slot >= h->n_cfg_slots) return fail("mg_write_config_slot: slot out of range");
+  MgConfig v;
+  try {
+    v = MgConfig::parse(cfg_blob, cfg_words);
+  } catch (const std::exception& ex) {
+    return fail(std::string("mg_write_config_slot: ") + ex.what());
+  }
+  if (mg_check_supported(v, "mg_write_config_slot")) return 1;
+  const MgConfig& c = h->cfg;
+  // what sizes buffers, LDS and the observation layout must match the configuration the handle was created with
+  auto differs = [&](const char* what) { return fail(std::string("mg_write_config_slot: the task's configuration differs from the handle's in ") + what); };
+  if (v.R != c.R) return differs("the number of resources");
+  if (v.A != c.A) return differs("num_agents");
+  if (v.T != c.T || v.obs_w != c.obs_w || v.obs_h != c.obs_h || v.token_base != c.token_base) return differs("the observation shape");
+  if (v.n_agent_slots != c.n_agent_slots || v.n_game_slots != c.n_game_slots || v.n_group_names != c.n_group_names) return differs("the statistics layout");
+  if (v.n_vibes != c.n_vibes || v.n_inv_tokens != c.n_inv_tokens) return differs("vibes / inventory token encoding");
+  if (v.actions.size() != c.actions.size()) return differs("the action space");
+  for (size_t i = 0; i < c.actions.size(); i++)
+    if (v.actions[i].kind != c.actions[i].kind || v.actions[i].arg != c.actions[i].arg) return differs("the action space");
+  if (v.cells.size() != c.cells.size()) return differs("the map cell table");
+  for (size_t i = 0; i < c.cells.size(); i++)
+    if (v.cells[i].kind != c.cells[i].kind || v.cells[i].idx != c.cells[i].idx) return differs("the map cell table");
+  if (v.groups.size() != c.groups.size() || v.walls.size() != c.walls.size() || v.assemblers.size() != c.assemblers.size() ||
+      v.chests.size() != c.chests.size())
+    return differs("the object types");
+  for (int i = 0; i < MG_F_COUNT; i++)
+    if (v.fid[i] != c.fid[i]) return differs("the observation feature ids");
+  if (v.fid_inv != c.fid_inv || v.fid_in != c.fid_in || v.fid_out != c.fid_out) return differs("the observation feature ids");
+  if (v.init_obs_passes != c.init_obs_passes) return differs("init_obs_passes");
+  if (mg_has_damage(v) && !mg_has_damage(c)) return differs("damage (the RNG window was sized without it)");
+  int ts[4];
+  mg_token_strides(v, ts);
+  if (h->maps_set && (ts[0] > h->ts[0] || ts[1] > h->ts[1] || ts[2] > h->ts[2] || ts[3] > h->ts[3]))
+    return differs("tokens per object (more than the pool was sized for)");
+  std::vector<int32_t> dcfg = mg_build_dcfg(v);
+  while (dcfg.size() % 4) dcfg.push_back(0);
+  KArgs& k = h->k;
+  if ((int)dcfg.size() > k.dc_stride || dcfg[DC_OBS_WORDS] > k.dc_obs_words)
+    return fail("mg_write_config_slot: the task's configuration stream (" + std::to_string(dcfg.size()) + " words, prefix " +
+                std::to_string(dcfg[DC_OBS_WORDS]) + ") exceeds the slot (" + std::to_string(k.dc_stride) + ", prefix " +
+                std::to_string(k.dc_obs_words) + "): raise headroom_words of mg_set_config_slots");
+  if (mg_use_device(h)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  dcfg.resize((size_t)k.dc_stride, 0);
+  HIPCHK(hipMemcpyAsync(const_cast<int*>(k.gdc) + (size_t)slot * k.dc_stride, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // (dcfg is a local)
+  // a task outside the wave-parallel / modifier-free fast paths moves the whole handle to the general kernels
+  if (k.fast && !mg_fast_eligible(v)) {
+    k.fast = 0;
+    h->kt.fast = 0;
+    h->fused = false;
+  }
+  if (mg_has_modifiers(v)) h->no_modifiers = false;
+  if (h->maps_set) {
+    std::vector<int> maps;
+    for (size_t m = 0; m < h->host_map_cfg.size(); m++)
+      if (h->host_map_cfg[m] == slot) maps.push_back((int)m);
+    if (mg_rebuild_templates(h, maps, st)) return 1;
+  }
+  return 0;
+}
+
+int mg_assign_map_configs(mg_handle* h, int n, const int32_t* map_ids, const int32_t* cfg_slots, void* stream) {
+  if (!h || (n > 0 && (!map_ids || !cfg_slots))) return fail("mg_assign_map_configs: NULL argument");
+  if (!h->maps_set || h->n_cfg_slots < 1 || !h->d_map_cfg) return fail("mg_assign_map_configs: call mg_set_config_slots and mg_set_maps first");
+  std::vector<int> maps;
+  for (int i = 0; i < n; i++) {
+    if (map_ids[i] < 0 || map_ids[i] >= h->k.P) return fail("mg_assign_map_configs: map id out of range");
+    if (cfg_slots[i] < 0 || cfg_slots[i] >= h->n_cfg_slots) return fail("mg_assign_map_configs: configuration slot out of range");
+  }
+  if (mg_use_device(h)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n; i++) {
+    h->host_map_cfg[(size_t)map_ids[i]] = cfg_slots[i];
+    maps.push_back(map_ids[i]);
+  }
+  // (P ints: re-upload the table; stream-ordered after the steps already queued)
+  HIPCHK(hipMemcpyAsync(h->d_map_cfg, h->host_map_cfg.data(), h->host_map_cfg.size() * 4, hipMemcpyHostToDevice, st));
+  return mg_rebuild_templates(h, maps, st);
 }
 
 int mg_set_map_max_steps(mg_handle* h, const int32_t* max_steps) {

@@ -43,6 +43,11 @@ struct KArgs {
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
   const int* map_max_steps;   // [P] episode length of each map (0 = the configuration's), or null: every map the configuration's
   int max_steps, max_steps_cfg;  // the current environment's / the configuration's max_steps
+  // Per-slot configurations (curriculum tasks: a task is a (configuration, map) pair): map slot m plays the stream at
+  // gdc + map_cfg[m] * dc_stride; null = one configuration for the whole pool.  dc_words / dc_obs_words are then the
+  // largest over the slots (LDS staging copies that many words from the slot's base; every slot is dc_stride long).
+  const int* map_cfg;            // [P] configuration slot of each map slot, or null
+  int dc_stride;
   int P, H, W, HW, NAmax, n_cells;  // HW = cell stride of one map in the pool (the largest map, even)
   int NW, NOBJ;            // wall types, objects per env (NW + A + NAmax)
   int NWINCELLS;           // cells of the observation window (obs_h * obs_w)
@@ -137,6 +142,12 @@ __device__ __forceinline__ void mg_use_map(KArgs& a, uint32_t map_id) {
   a.H = d.x;
   a.W = d.y;
   int ms = a.max_steps_cfg;
+  if (a.map_cfg) {  // (before any use of a.dc: the callers stage / capture the stream after this call)
+    const int* base = a.gdc + (size_t)a.map_cfg[map_id] * (size_t)a.dc_stride;
+    a.gdc = base;
+    a.dc = base;
+    ms = base[DC_MAX_STEPS];
+  }
   if (a.map_max_steps) {
     const int m = a.map_max_steps[map_id];
     if (m > 0) ms = m;

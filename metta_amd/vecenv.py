@@ -91,6 +91,7 @@ class MettaGridDeviceVecEnv:
         init_obs_passes: int = 2,
         device_maps: bool = False,
         map_refresh_every: Optional[int] = None,
+        config_slots: int = 0,
     ):
         self.cfg = cfg
         self.policy_env_info = PolicyEnvInterface.from_mg_cfg(cfg)
@@ -118,7 +119,9 @@ class MettaGridDeviceVecEnv:
         # 2 = the Puffer path: the step-0 observations are computed by the ctor and again by set_buffers;
         # 1 = a bare `Simulation` without shared buffers
         self.compiled = compile_game(cfg, init_obs_passes=init_obs_passes)
-        self.batch = MettaGridBatch(cfg, num_envs, maps, device=device, compiled=self.compiled)
+        self.batch = MettaGridBatch(
+            cfg, num_envs, maps, device=device, compiled=self.compiled, init_obs_passes=init_obs_passes, config_slots=config_slots
+        )
         self.batch.set_auto_reset(True, int(num_envs) if self.device_maps else 1)
         self.num_environments = int(num_envs)
         self.agents_per_env = game.num_agents
@@ -325,12 +328,19 @@ class MettaGridDeviceVecEnv:
                         "map_w": int(b.map_dims[info["map_id"], 1]),
                         "map_h": int(b.map_dims[info["map_id"], 0]),
                         "steps": info["current_step"],
-                        "max_steps": self.cfg.game.max_steps,
+                        "max_steps": self._slot_max_steps(info["map_id"]),
                         "completion_time": time.time(),
                     },
                 }
             )
+            self._episode_finished(e, info["map_id"], mean_reward, self.infos[-1])
 
+
+    def _slot_max_steps(self, map_slot: int) -> int:
+        return int(self.cfg.game.max_steps)
+
+    def _episode_finished(self, env: int, map_slot: int, mean_reward: float, info: dict, current_slot: int = -1) -> None:
+        """Hook: environment `env` finished an episode on map slot `map_slot` (CurriculumDeviceVecEnv completes tasks)."""
 
     def _chest_deposits(self, game_stats: dict) -> dict:
         # stats_tracker.py:58-61: hearts deposited in chests, per mission label
@@ -365,10 +375,109 @@ class MettaGridDeviceVecEnv:
                     "attributes": {
                         "seed": int(table[e, 2]), "map_w": int(b.map_dims[prev_map, 1]),
                         "map_h": int(b.map_dims[prev_map, 0]), "steps": steps,
-                        "max_steps": self.cfg.game.max_steps, "completion_time": time.time(),
+                        "max_steps": self._slot_max_steps(prev_map), "completion_time": time.time(),
                     },
                 }
             )
+            self._episode_finished(e, prev_map, float(ep_rewards.mean()), self.infos[-1], current_slot=int(table[e, 3]))
+
+
+class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
+    """`CurriculumEnv` (metta/cogworks/curriculum/curriculum_env.py:10-142) for the device vecenv: every episode of every
+    environment plays a task drawn from `curriculum`, finished episodes complete their task with the mean episode
+    reward and update the curriculum, and `env_curriculum/*` statistics ride on the infos every 50 steps.
+
+    `curriculum` offers what the reference's `Curriculum` does: `get_task()` -> task with `get_env_cfg()`, `complete(r)`
+    and `_task_id`; `update_task_performance(task_id, r)`; `stats()`.
+
+    A task is a (configuration, map) pair in the pool: 2E map slots and 2E configuration slots, environment e alternates
+    between slots e and e + E.  While an episode runs on one slot the host writes the NEXT task into the idle twin
+    (`mg_write_config_slot`), so the switch at an episode end happens on the device without waiting for the host; the
+    price is one episode of lag in what the curriculum knows when it picks that task.  All tasks must share the shapes
+    of the first task's configuration (agents, resources, actions, object types): rewards, limits, inventories,
+    protocols, attack costs, max_steps may vary -- what the reference's arena / navigation curricula bucket over."""
+
+    def __init__(self, curriculum, num_envs: int, maps: Optional[Sequence] = None, num_maps: int = 64, device: int = 0,
+                 seed: int = 0, early_reset: bool = False, map_seed: int = 0, init_obs_passes: int = 2,
+                 device_maps: bool = False, map_refresh_every: Optional[int] = None):  # fmt: skip
+        self._curriculum = curriculum
+        self._current_task = curriculum.get_task()  # (the reference draws one in its constructor too, :32)
+        cfg = self._current_task.get_env_cfg()
+        E = int(num_envs)
+        if not device_maps:
+            if maps is None:
+                rng = np.random.default_rng(map_seed)
+                maps = [cfg.game.map_builder.build(rng) for _ in range(num_maps)]
+            maps = [maps[s % len(maps)] for s in range(2 * E)]  # every environment owns two slots of the pool
+        super().__init__(cfg, E, maps=maps, device=device, seed=seed, early_reset=early_reset, map_seed=map_seed,
+                         init_obs_passes=init_obs_passes, device_maps=device_maps, map_refresh_every=map_refresh_every,
+                         config_slots=2 * E)  # fmt: skip
+        self.batch.set_auto_reset(True, E)
+        self.batch.assign_map_configs(np.arange(2 * E), np.arange(2 * E))
+        self._slot_task: list = [None] * (2 * E)
+        self._blob_cache: dict = {}
+        self._stats_update_counter = 0
+        self._stats_update_frequency = 50  # curriculum_env.py:36
+        self._first_reset_done = False
+        self.tasks_completed = 0
+
+    def _write_task(self, slot: int, task) -> None:
+        key = getattr(task, "_task_id", None)
+        comp = self._blob_cache.get(key) if key is not None else None
+        if comp is None:
+            comp = compile_game(task.get_env_cfg(), init_obs_passes=self.batch._init_obs_passes)
+            if key is not None:
+                if len(self._blob_cache) > 4096:
+                    self._blob_cache.clear()
+                self._blob_cache[key] = comp
+        self.batch.write_config_slot(slot, comp)
+        self._slot_task[slot] = task
+
+    def _new_task(self, slot: int) -> None:
+        # curriculum_env.py:111-126: up to ten attempts at a task whose configuration is valid
+        for attempt in range(10):
+            task = self._curriculum.get_task()
+            try:
+                self._write_task(slot, task)
+                return
+            except Exception:
+                if attempt == 9:
+                    raise
+
+    def async_reset(self, seed: Optional[int] = None) -> None:
+        for slot in range(2 * self.num_environments):
+            self._new_task(slot)
+        self._current_task = self._slot_task[0]
+        super().async_reset(seed)
+        if not self._first_reset_done:  # curriculum_env.py:87-92
+            self.infos.append({"env_curriculum/" + k: v for k, v in self._curriculum.stats().items()})
+            self._first_reset_done = True
+
+    def send(self, actions) -> None:
+        super().send(actions)
+        self._stats_update_counter += 1
+        if self._stats_update_counter >= self._stats_update_frequency and self.infos:  # curriculum_env.py:48-63,131-140
+            for k, v in self._curriculum.stats().items():
+                self.infos[0]["env_curriculum/" + k] = v
+            self._stats_update_counter = 0
+
+    def _slot_max_steps(self, map_slot: int) -> int:
+        task = self._slot_task[map_slot]
+        return int(task.get_env_cfg().game.max_steps) if task is not None else int(self.cfg.game.max_steps)
+
+    def _episode_finished(self, env: int, map_slot: int, mean_reward: float, info: dict, current_slot: int = -1) -> None:
+        task = self._slot_task[map_slot]
+        if task is not None:  # curriculum_env.py:105-109
+            task.complete(mean_reward)
+            self._curriculum.update_task_performance(task._task_id, mean_reward)
+            self.tasks_completed += 1
+        if current_slot == map_slot:
+            return  # (a host that fell a whole episode behind: the environment is back on this slot; leave it)
+        self._new_task(map_slot)
+
+    def set_stats_update_frequency(self, frequency: int) -> None:
+        self._stats_update_frequency = max(1, frequency)
+        self._stats_update_counter = 0
 
 
 class AsyncDeviceVecEnv:
