@@ -32,7 +32,7 @@ from metta_amd.id_map import FIXED_FEATURES, encoder_num_inventory_tokens
 from metta_amd.umap import order_from_inserts, order_from_pydict, std_hash_string
 
 MG_BLOB_MAGIC = 0x4D474231
-MG_BLOB_VERSION = 3
+MG_BLOB_VERSION = 4
 
 ACT_NOOP, ACT_MOVE, ACT_CHANGE_VIBE = 0, 1, 2
 CELL_WALL, CELL_AGENT, CELL_ASSEMBLER, CELL_CHEST = 1, 2, 3, 4
@@ -150,8 +150,9 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
             "clipper: iteration over std::set<Assembler*> is pointer-ordered in the reference (not reproducible); "
             "out of scope for the step path (SURVEY §8a A19)"
         )
-    if game.collectives:
-        raise NotImplementedError("collectives are a second-wave object set (SURVEY §8a A19)")
+    # collectives (mettagrid_c_config.py:544-575; BIND/mettagrid_c.cpp:95-128): only what the step path can observe --
+    # the statistics `Agent::compute_stat_rewards` reads through `getCollective()` (agent.cpp:115-117)
+    coll_id = {c.name: i for i, c in enumerate(game.collectives)}
 
     resource_names = list(game.resource_names)
     rid = {n: i for i, n in enumerate(resource_names)}
@@ -403,6 +404,15 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
             w.f(stat_rewards[name])
             w.i(1 if name in stat_max else 0)
             w.f(stat_max.get(name, 0.0))
+            # what a collective's StatsTracker can hold under this name (collective.hpp:46-52,101-108)
+            if name == "aligned.agent":
+                w.i(1, 0)
+            elif name.startswith("collective.") and name.endswith(".deposited") and name[11:-10] in rid:
+                w.i(2, rid[name[11:-10]])
+            else:
+                w.i(0, 0)
+        prefix = "collective:"  # membership by tag, in tag order; the last existing one stays (alignable.cpp:5-16)
+        w.list([coll_id[t[len(prefix):]] for t in first.tags if t.startswith(prefix) and t[len(prefix):] in coll_id])
         goal: list[int] = []
         seen: set[str] = set()
         for name in order:  # BIND/mettagrid_c.cpp:371-392
@@ -491,6 +501,9 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
             w.i(v)
             w.kv(_ordered_items(deltas))
 
+    w.i(len(game.collectives))
+    for cc in game.collectives:
+        w.kv(_ordered_items({rid[k]: int(v) for k, v in cc.inventory.initial.items() if k in rid}))
     w.i(len(agent_slot_names[0]) if agent_slot_names else 0, len(game_slot_names))
     w.i(MG_BLOB_MAGIC)
 

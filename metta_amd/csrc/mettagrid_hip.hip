@@ -253,7 +253,7 @@ static int dalloc(mg_handle* h, T** p, size_t n, bool map_alloc = false) {
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return "mettagrid_hip 0.1 (gfx950; blob v" "3" ")"; }
+const char* mg_version(void) { return "mettagrid_hip 0.1 (gfx950; blob v" "4" ")"; }
 
 int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int device_id, mg_handle** out) {
   if (!out) return fail("mg_create: out is NULL");

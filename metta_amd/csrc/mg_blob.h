@@ -18,7 +18,7 @@
 #include <vector>
 
 #define MG_BLOB_MAGIC 0x4D474231  // 'MGB1'
-#define MG_BLOB_VERSION 3
+#define MG_BLOB_VERSION 4
 
 enum MgActionKind { MG_ACT_NOOP = 0, MG_ACT_MOVE = 1, MG_ACT_CHANGE_VIBE = 2 };
 enum MgCellKind { MG_CELL_EMPTY = 0, MG_CELL_WALL = 1, MG_CELL_AGENT = 2, MG_CELL_ASSEMBLER = 3, MG_CELL_CHEST = 4 };
@@ -104,12 +104,17 @@ struct MgStatReward {
   float weight;
   int32_t has_max;
   float max;
+  // what `getCollective()->stats.get(stat_name)` can find (agent.cpp:115-117; collective.hpp:46-52,101-108):
+  // 0 nothing, 1 "aligned.agent", 2 "collective.<coll_res>.deposited"
+  int32_t coll_kind, coll_res;
 };
 struct MgGroup {
   int32_t group_id, group_name_idx, freeze_duration, initial_vibe;
   std::vector<int32_t> tags;
   MgInventoryCfg inv;
   std::vector<MgStatReward> stat_rewards;  // iteration order of the string-keyed map (agent.cpp:110)
+  std::vector<int32_t> collectives;        // collective ids named by the "collective:<name>" tags, in tag order: the
+                                           // constructor calls setCollective for each (mettagrid_c.cpp:102-127), the last stays
   std::vector<int32_t> goal_values;        // goal token values, precomputed as BIND/mettagrid_c.cpp:363-395
   std::vector<std::pair<int32_t, MgKVList>> regen;  // vibe -> (item, delta) list
   std::vector<int32_t> diversity;
@@ -156,6 +161,7 @@ struct MgTransferEffect {
 };
 
 struct MgConfig {
+  std::vector<MgKVList> collective_initial;  // per collective: (item, amount)
   int32_t R = 0, A = 0, obs_w = 0, obs_h = 0, T = 0, token_base = 256, max_steps = 0, episode_truncates = 0;
   int32_t g_completion = 1, g_last_action = 1, g_last_reward = 1, g_compass = 0, g_goal = 0;
   int32_t protocol_details_obs = 1, regen_interval = 0, init_obs_passes = 1, n_vibes = 0, n_group_names = 0;
@@ -276,7 +282,9 @@ struct MgConfig {
         g.stat_rewards.resize((size_t)ns);
         for (auto& s : g.stat_rewards) {
           s.agent_slot = r.i32(); s.game_slot = r.i32(); s.weight = r.f32(); s.has_max = r.i32(); s.max = r.f32();
+          s.coll_kind = r.i32(); s.coll_res = r.i32();
         }
+        g.collectives = r.list();
         g.goal_values = r.list();
         int32_t nr = r.i32();
         g.regen.resize((size_t)nr);
@@ -328,6 +336,11 @@ struct MgConfig {
         ch.vibe_transfers.resize((size_t)nv);
         for (auto& v : ch.vibe_transfers) { v.first = r.i32(); v.second = r.kvlist(); }
       }
+    }
+    {  // collectives (collective.hpp:33-42): initial inventory, in the configuration map's iteration order
+      int32_t nc = r.i32();
+      c.collective_initial.resize((size_t)nc);
+      for (auto& kv : c.collective_initial) kv = r.kvlist();
     }
     c.n_agent_slots = r.i32();
     c.n_game_slots = r.i32();

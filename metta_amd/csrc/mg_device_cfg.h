@@ -28,7 +28,9 @@ enum MgDc {
 enum MgGr {
   GR_GROUP_ID = 0, GR_NAME_IDX, GR_FREEZE_DURATION, GR_INITIAL_VIBE, GR_OFF_TAGS, GR_N_LIMITS, GR_OFF_LIMITS,
   GR_OFF_LIMIT_OF, GR_OFF_MODIFIER, GR_OFF_LIMITS_ORDER, GR_OFF_INITIAL, GR_OFF_STAT_REWARDS, GR_OFF_GOAL,
-  GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_OFF_DMG_THRESHOLD, GR_OFF_DMG_RESOURCES, GR_WORDS
+  GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_OFF_DMG_THRESHOLD, GR_OFF_DMG_RESOURCES,
+  GR_COLLECTIVE,  // the collective the group's agents end up in (last "collective:<name>" tag), or -1
+  GR_WORDS
 };
 enum MgWr { WR_TYPE_ID = 0, WR_VIBE, WR_OFF_TAGS, WR_WORDS };
 // chest record: CR_GROUP = index of the pseudo group record (after the agent groups) that carries the chest's inventory
@@ -40,6 +42,7 @@ enum MgAr {
 };
 enum MgPr { PR_MIN_AGENTS = 0, PR_COOLDOWN, PR_OFF_VIBES, PR_OFF_IN, PR_OFF_OUT, PR_OFF_IN_S, PR_OFF_OUT_S, PR_WORDS };
 
+#define MG_SR_WORDS 7  // stat-reward entry: agent slot, game slot, weight, has_max, max, collective constant, aligned flag
 #define MGD_MAX_R 16  // device inventories hold up to 16 resources (uint16 amounts + 16-entry order list)
 
 struct MgDcBuilder {
@@ -139,12 +142,24 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
       rec[GR_OFF_LIMITS_ORDER] = b.put_kv(inv.limits_map_order);
       rec[GR_OFF_INITIAL] = b.put_kv(inv.initial);
       {
-        int o = b.reserve(1 + 5 * (int)g.stat_rewards.size());
+        // Collective statistics never change during an episode (nothing on the step path touches a collective's
+        // inventory or membership): what `getCollective()->stats.get(name)` adds (agent.cpp:115-117) is a constant
+        // of the entry -- "collective.<r>.deposited" = the initial amount (collective.hpp:36-41,101-108; uint16
+        // inventory) -- or, for "aligned.agent", the member count, which the reset kernel leaves in the agent record.
+        const int coll = g.collectives.empty() ? -1 : g.collectives.back();
+        rec[GR_COLLECTIVE] = coll;
+        int o = b.reserve(1 + MG_SR_WORDS * (int)g.stat_rewards.size());
         b.w[(size_t)o] = (int32_t)g.stat_rewards.size();
         for (size_t i = 0; i < g.stat_rewards.size(); i++) {
           const auto& s = g.stat_rewards[i];
-          int32_t* p = &b.w[(size_t)o + 1 + 5 * i];
+          int32_t* p = &b.w[(size_t)o + 1 + MG_SR_WORDS * i];
           p[0] = s.agent_slot; p[1] = s.game_slot; p[2] = mg_f32_bits(s.weight); p[3] = s.has_max; p[4] = mg_f32_bits(s.max);
+          float cv = 0.f;
+          if (coll >= 0 && s.coll_kind == 2)
+            for (const auto& kv : c.collective_initial[(size_t)coll])
+              if (kv.k == s.coll_res && kv.v > 0) cv = (float)(kv.v > 65535 ? 65535 : kv.v);
+          p[5] = mg_f32_bits(cv);
+          p[6] = (coll >= 0 && s.coll_kind == 1) ? 1 : 0;
         }
         rec[GR_OFF_STAT_REWARDS] = o;
       }

@@ -658,6 +658,13 @@ __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e
     ag.group = (uint8_t)s.z;
     ag.vibe = (uint8_t)group_rec(dc, s.z)[GR_INITIAL_VIBE];
     ag.nb = 1;
+    {  // members of the agent's collective on this map ("aligned.agent", collective.hpp:46-52)
+      const int coll = group_rec(dc, s.z)[GR_COLLECTIVE];
+      int n = 0;
+      if (coll >= 0)
+        for (int j = 0; j < a.A; j++) n += group_rec(dc, spawn[j].z)[GR_COLLECTIVE] == coll ? 1 : 0;
+      ag.aligned = (float)n;
+    }
     l.ag[i] = ag;
   }
   int nasm = a.map_nasm[map_id];
@@ -823,7 +830,7 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
     if (ns > 0) {
       float total = 0.f;
       for (int q = 0; q < ns; q++) {
-        const int* sr = dc + os + 1 + 5 * q;
+        const int* sr = dc + os + 1 + MG_SR_WORDS * q;
         int aslot = sr[0], gslot = sr[1];
         float v = 0.f;
         if (aslot >= 0) {
@@ -846,6 +853,7 @@ __device__ inline void mg_rewards_and_flags(const KArgs& a, const Lds& l, int e,
         if (gslot >= 0)
           v += gslot < 3 ? l.tokacc[gslot]
                          : (FUSED ? __hip_atomic_load(&gs_[gslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : gs_[gslot]);
+        if (gr[GR_COLLECTIVE] >= 0) v += sr[6] ? me->aligned : __int_as_float(sr[5]);  // agent.cpp:115-117
         float rew = v * __int_as_float(sr[2]);
         if (sr[3]) {
           float mx = __int_as_float(sr[4]);

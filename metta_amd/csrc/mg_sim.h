@@ -53,7 +53,8 @@ struct __align__(16) DAgent {  // 112 bytes; one per agent, [E][A] in HBM, stage
   // action.<noop|move|change_vibe>.success / .failed; action.failed is their sum; max_swm above.
   // mg_episode_stats merges them back into the reference's key set.
   uint32_t succ[3], fail[3];
-  uint32_t pad2[2];
+  float aligned;  // the collective's "aligned.agent" statistic: its members on this map (constant over an episode)
+  uint32_t pad2;
 };
 static_assert(sizeof(DAgent) == 112, "DAgent layout");
 

@@ -29,7 +29,8 @@ sys.path.insert(0, str(ROOT))
 
 from oracle.gen_golden import GOLD, digest, encode_names, install_reference_shims  # noqa: E402
 
-SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112]
+SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115]
+COLLECTIVE_SEEDS = {113, 114, 115}  # + collectives: membership by tag, stat rewards on the collective's statistics
 STEPS = 200
 
 
@@ -47,6 +48,7 @@ def features_of(game) -> dict:
         "limit_modifiers": any(l.modifiers for a in game.agents for l in a.inventory.limits.values()),
         "chest_search": any(a.chest_search_distance > 0 for a in asm),
         "move_costs": bool(game.actions.move.consumed_resources),
+        "collectives": bool(game.collectives) and any("aligned.agent" in a.rewards.stats for a in game.agents),
         "token_base": int(game.obs.token_value_base),
     }
 
@@ -63,7 +65,7 @@ def main() -> None:
 
     covered: dict[str, int] = {}
     for seed in SEEDS:
-        cfg = rand_cfg(np.random.RandomState(seed), device_safe=True)
+        cfg = rand_cfg(np.random.RandomState(seed), device_safe=True, collectives=seed in COLLECTIVE_SEEDS)
         game = cfg.game
         grid = np.asarray(game.map_builder.build(np.random.default_rng(seed)))
         dump = game.model_dump(mode="json", exclude={"map_builder"})
@@ -107,7 +109,7 @@ def main() -> None:
         print(f"wrote feature_{seed}.npz", {k: v for k, v in feats.items() if v})
     print("feature coverage over the fixture set:", covered)
     need = ["attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
-            "limit_modifiers", "chest_search"]
+            "limit_modifiers", "chest_search", "collectives"]
     missing = [k for k in need if not covered.get(k)]
     assert not missing, f"no fixture exercises {missing}: extend SEEDS"
 

@@ -281,6 +281,16 @@ struct Agent {
   Stats stats;
   std::vector<uint8_t> presence;
   size_t diversity = 0;
+  int collective = -1;  // Alignable::_collective
+};
+// Collective (collective.hpp:19-109): the part of it the step path can observe is its StatsTracker, read by
+// Agent::compute_stat_rewards: "aligned.<type_name>" kept by addMember / removeMember, and
+// "collective.<resource>.deposited" written by on_inventory_change while the constructor fills the inventory.
+struct CollectiveInst {
+  std::vector<int> members;          // agent indices
+  int aligned_agents = 0;            // _aligned_counts["agent"]
+  float stat_aligned_agent = 0.f;    // stats "aligned.agent"
+  std::vector<float> stat_deposited; // stats "collective.<r>.deposited"
 };
 struct AssemblerInst {
   int r, c, cfg;
@@ -307,6 +317,7 @@ struct Env {
   std::vector<Agent> agents;
   std::vector<AssemblerInst> assemblers;
   std::vector<ChestInst> chests;
+  std::vector<CollectiveInst> collectives;
   Stats game;
   MT19937 rng;
   uint32_t current_step = 0;
@@ -553,6 +564,38 @@ void Env::init(const int32_t* blob, size_t n, const uint8_t* map, int h, int w, 
       }
       cell(r, c) = (int32_t)id;
     }
+  // collectives (mettagrid_c.cpp:95-128): built after the grid; objects in id order call setCollective once per
+  // "collective:<name>" tag, in tag order (alignable.cpp:5-16: leave the old one, join the new one)
+  collectives.assign(cfg.collective_initial.size(), CollectiveInst{});
+  for (size_t k = 0; k < collectives.size(); k++) {
+    collectives[k].stat_deposited.assign((size_t)std::max(cfg.R, 1), 0.f);
+    for (const auto& kv : cfg.collective_initial[k])
+      if (kv.v > 0)  // collective.hpp:36-41: ignore_limits; Inventory clamps to uint16 (inventory.cpp:41-56)
+        collectives[k].stat_deposited[(size_t)kv.k] += (float)std::min(kv.v, 65535);
+  }
+  for (size_t id = 1; id < objects.size(); id++) {
+    if (objects[id].kind != MG_CELL_AGENT) continue;  // only agents are Alignable (agent.hpp:21)
+    const int ai2 = objects[id].idx;
+    Agent& a = agents[(size_t)ai2];
+    for (int k : cfg.groups[(size_t)a.group].collectives) {
+      if (a.collective >= 0) {  // removeMember (collective.hpp:57-70)
+        CollectiveInst& old = collectives[(size_t)a.collective];
+        auto it = std::find(old.members.begin(), old.members.end(), ai2);
+        if (it != old.members.end()) {
+          old.members.erase(it);
+          old.aligned_agents--;
+          old.stat_aligned_agent = old.aligned_agents <= 0 ? 0.0f : (float)old.aligned_agents;
+        }
+      }
+      a.collective = k;
+      CollectiveInst& c2 = collectives[(size_t)k];  // addMember (collective.hpp:46-54)
+      if (std::find(c2.members.begin(), c2.members.end(), ai2) == c2.members.end()) {
+        c2.members.push_back(ai2);
+        c2.aligned_agents++;
+        c2.stat_aligned_agent = (float)c2.aligned_agents;
+      }
+    }
+  }
   size_t A = agents.size();
   obs.assign(A * (size_t)cfg.T * 3, 0xFF);
   terminals.assign(A, 0);
@@ -1154,6 +1197,13 @@ void Env::compute_stat_rewards(size_t ai) {
   for (const auto& sr : g.stat_rewards) {
     float v = a.stats.get(sr.agent_slot);
     v += game.get(sr.game_slot);
+    if (a.collective >= 0) {  // agent.cpp:115-117
+      const CollectiveInst& c2 = collectives[(size_t)a.collective];
+      float cv = 0.f;
+      if (sr.coll_kind == 1) cv = c2.stat_aligned_agent;
+      else if (sr.coll_kind == 2) cv = c2.stat_deposited[(size_t)sr.coll_res];
+      v += cv;
+    }
     float rew = v * sr.weight;
     if (sr.has_max) rew = std::min(rew, sr.max);
     total += rew;

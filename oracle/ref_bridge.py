@@ -53,8 +53,8 @@ def to_ref_game_config(game) -> Any:
     from metta_amd.config import AgentConfig, AssemblerConfig, ChestConfig, WallConfig
 
     C = load_reference_module()
-    if game.clipper is not None or game.collectives:
-        raise NotImplementedError("clipper / collectives are outside the step path scope")
+    if game.clipper is not None:
+        raise NotImplementedError("clipper is outside the step path scope")
     resource_names = list(game.resource_names)
     rid = {n: i for i, n in enumerate(resource_names)}
     vibe_names = [v.name for v in game.actions.change_vibe.vibes]
@@ -241,11 +241,29 @@ def to_ref_game_config(game) -> Any:
         actions=actions,
         objects=objects,
         tag_id_map={i: t for t, i in tag_id.items()},
-        collectives={},
+        collectives=_collectives(C, game, rid),
         protocol_details_obs=game.protocol_details_obs,
         inventory_regen_interval=game.inventory_regen_interval,
         token_value_base=game.obs.token_value_base,
     )
+
+
+def _collectives(C, game, rid) -> dict:
+    """mettagrid_c_config.py:544-575."""
+    out = {}
+    for cc in game.collectives:
+        inv = C.InventoryConfig()
+        defs = []
+        for lim in cc.inventory.limits.values():
+            ids = [rid[n] for n in lim.resources if n in rid]
+            if ids:
+                defs.append(C.LimitDef(ids, lim.limit, {rid[n]: b for n, b in lim.modifiers.items() if n in rid}))
+        inv.limit_defs = defs
+        c = C.CollectiveConfig(cc.name)
+        c.inventory_config = inv
+        c.initial_inventory = {rid[k]: int(v) for k, v in cc.inventory.initial.items() if k in rid}
+        out[cc.name] = c
+    return out
 
 
 class RefEnv:

@@ -42,7 +42,46 @@ RES = ["ore_red", "battery_red", "heart", "armor", "laser", "gear", "energy"]
 VIB = ["default", "weapon", "shield", "armor", "give", "take", "heart", "gear"]
 
 
-def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridConfig:
+def add_collectives(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridConfig:
+    """Collectives (collective.hpp:19-109) as the step path sees them: teams join by tag, and stat rewards name the
+    collective's statistics (`aligned.agent`, `collective.<r>.deposited`; agent.cpp:115-117)."""
+    from metta_amd.config import CollectiveConfig
+
+    game = cfg.game
+    R = list(game.resource_names)
+    names = ["red", "blue"][: int(rs.randint(1, 3))]
+    game.collectives = [
+        CollectiveConfig(
+            name=n,
+            inventory=InventoryConfig(initial={R[int(rs.randint(len(R)))]: int(rs.randint(0, 40)), R[0]: int(rs.randint(1, 9))}),
+        )
+        for n in names
+    ]
+    seen: set[int] = set()
+    for ag in game.agents:  # (one config object per team)
+        if id(ag) in seen:
+            continue
+        seen.add(id(ag))
+        mode = int(rs.randint(4))
+        if mode == 0:
+            continue  # a team outside every collective
+        tags = ["collective:" + names[int(rs.randint(len(names)))]]
+        if mode == 2:
+            tags = ["collective:nowhere"] + tags  # a name no collective has: ignored (mettagrid_c.cpp:122-125)
+        if mode == 3 and len(names) > 1:
+            tags = ["collective:red", "collective:blue"]  # joins red, then leaves it for blue (alignable.cpp:5-16)
+        ag.tags = list(ag.tags) + tags
+        ag.rewards.stats = dict(ag.rewards.stats)
+        ag.rewards.stats["aligned.agent"] = float(rs.choice([0.05, 0.25, -0.1]))
+        ag.rewards.stats[f"collective.{R[0]}.deposited"] = float(rs.choice([0.01, 0.5]))
+        ag.rewards.stats[f"collective.{R[1]}.deposited"] = 0.125
+        if rs.randint(2):
+            ag.rewards.stats_max = dict(ag.rewards.stats_max)
+            ag.rewards.stats_max[f"collective.{R[0]}.deposited"] = 1.5
+    return cfg
+
+
+def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: bool = False) -> MettaGridConfig:
     R = RES[: rs.randint(3, len(RES) + 1)]
 
     def rr():
@@ -177,7 +216,8 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False) -> MettaGridC
         ),
         inventory_regen_interval=int(rs.choice([0, 1, 3])), protocol_details_obs=bool(rs.randint(4)), map_builder=mb,
     )  # fmt: skip
-    return MettaGridConfig(game=game)
+    cfg = MettaGridConfig(game=game)
+    return add_collectives(cfg, rs) if collectives else cfg
 
 
 def fuzz_actions(rs: np.random.RandomState, game, n_actions: int, invalid: bool = True) -> np.ndarray:

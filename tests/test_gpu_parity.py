@@ -95,10 +95,10 @@ def test_arena_vs_oracle(path_env, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("seed", list(range(40)))
+@pytest.mark.parametrize("seed", list(range(48)))
 def test_fuzz_vs_oracle(seed):
     rs = np.random.RandomState(seed)
-    cfg = rand_cfg(rs, device_safe=True)
+    cfg = rand_cfg(rs, device_safe=True, collectives=seed >= 40)  # 40..47: + collectives and rewards on their statistics
     game = cfg.game
     passes = int(rs.randint(1, 3))
     maps = [game.map_builder.build(np.random.default_rng(1000 * seed + i)) for i in range(3)]
@@ -163,7 +163,7 @@ def test_golden_arena(name):
     b.close()
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112])
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115])
 def test_golden_feature_families(seed):
     """tests/golden/feature_<seed>.npz: configurations with attack / armor / loot / freeze, transfer, chests, damage,
     regeneration, partial usage ... converted by the reference's REAL `convert_to_cpp_game_config` and stepped by its
