@@ -42,6 +42,11 @@ const char* mg_last_error(void);
 /* Library version / build info string. */
 const char* mg_version(void);
 
+/* Resources an inventory of this build can hold: 16 for libmettagrid_hip.so, 32 for libmettagrid_hip_r32.so (the
+ * same sources with wider agent records).  The reference takes any `resource_names`
+ * (config/mettagrid_config.py:522-535); observation feature ids (uint8) bound it near 60 in practice. */
+int mg_max_resources(void);
+
 /* Create E environments from a packed game configuration (the int32 stream of csrc/mg_blob.h, written by
  * metta_amd/compile.py).  Replaces `MettaGrid::MettaGrid(GameConfig, map, seed)` (mettagrid_c.cpp:46-155) for the
  * config part; maps and seeds arrive through mg_set_maps / mg_reset.  `device_id` < 0 = current device. */

@@ -92,9 +92,10 @@ class MettaGridBatch:
         import torch
 
         self._torch = torch
-        self.L = native.load()
         self.cfg = cfg
         self.compiled = compiled or compile_game(cfg, init_obs_passes=init_obs_passes)
+        # inventories of up to 16 resources: libmettagrid_hip.so; 17..32: the wide-inventory build of the same sources
+        self.L = native.load_for(len(self.compiled.resource_names))
         self.num_envs = int(num_envs)
         self.num_agents = self.compiled.num_agents
         self.device_index = int(device)
@@ -102,15 +103,15 @@ class MettaGridBatch:
         torch.cuda.set_device(self.device_index)
         blob = np.ascontiguousarray(self.compiled.blob, dtype=np.int32)
         self._h = ct.c_void_p()
-        native.check(self.L.mg_create(_p(blob, ct.c_int32), blob.size, self.num_envs, self.device_index, ct.byref(self._h)))
+        self._check(self.L.mg_create(_p(blob, ct.c_int32), blob.size, self.num_envs, self.device_index, ct.byref(self._h)))
         self._owner = _HandleOwner(self.L, self._h)
         self.config_slots = int(config_slots)
         self._init_obs_passes = int(init_obs_passes)  # (tasks are compiled like the handle's own configuration)
         if self.config_slots > 0:  # per-slot configurations (curriculum tasks): before the pool, which is sized for them
-            native.check(self.L.mg_set_config_slots(self._h, self.config_slots, int(config_headroom_words)))
+            self._check(self.L.mg_set_config_slots(self._h, self.config_slots, int(config_headroom_words)))
         self.set_maps(maps)
         b = native.MgBuffers()
-        native.check(self.L.mg_get_buffers(self._h, ct.byref(b)))
+        self._check(self.L.mg_get_buffers(self._h, ct.byref(b)))
         N, T = self.num_envs * self.num_agents, self.compiled.num_tokens
         self.num_actions = int(b.num_actions)
 
@@ -129,6 +130,9 @@ class MettaGridBatch:
         self.action_success = alias(b.action_success, (N,), "|b1", torch.bool)
         if seeds is not None or map_ids is not None:
             self.reset(seeds=seeds, map_ids=map_ids)
+
+    def _check(self, rc: int) -> None:
+        native.check(rc, self.L)
 
     # ---- maps / reset / step ---------------------------------------------------------------------------
     def set_maps(self, maps: Sequence) -> None:
@@ -153,12 +157,12 @@ class MettaGridBatch:
         self.map_height, self.map_width = int(self.map_dims[:, 0].max()), int(self.map_dims[:, 1].max())
         if len({e.shape for e in enc}) == 1:
             pool = np.ascontiguousarray(np.stack(enc), dtype=np.uint8)
-            native.check(self.L.mg_set_maps(self._h, _p(pool, ct.c_uint8), pool.shape[0], pool.shape[1], pool.shape[2]))
+            self._check(self.L.mg_set_maps(self._h, _p(pool, ct.c_uint8), pool.shape[0], pool.shape[1], pool.shape[2]))
         else:  # maps of different sizes (navigation suite): back to back, with their dimensions
             flat = np.ascontiguousarray(np.concatenate([e.reshape(-1) for e in enc]), dtype=np.uint8)
             hs = np.ascontiguousarray(self.map_dims[:, 0])
             ws = np.ascontiguousarray(self.map_dims[:, 1])
-            native.check(
+            self._check(
                 self.L.mg_set_maps_ragged(self._h, _p(flat, ct.c_uint8), len(enc), _p(hs, ct.c_int32), _p(ws, ct.c_int32))
             )
 
@@ -167,7 +171,7 @@ class MettaGridBatch:
         reference's `RandomMapBuilder` / MapGen `Random` scene distribution (random_map.py:29-96, scenes/random.py:19-69)
         without a host copy.  `refresh_maps()` redraws used, idle slots."""
         e = spec.encode(self.compiled)
-        native.check(
+        self._check(
             self.L.mg_set_generated_maps(
                 self._h, e["height"], e["width"], e["fill_code"], len(e["rooms"]), _p(e["rooms"], ct.c_int32),
                 _p(e["room_sym_begin"], ct.c_int32), _p(e["sym_code"], ct.c_int32), _p(e["sym_count"], ct.c_int32),
@@ -186,12 +190,12 @@ class MettaGridBatch:
         2E slots and `set_auto_reset(True, map_stride=E)` each environment alternates between two slots, and a refresh
         once per episode gives every episode a new map, like the reference's per-episode `map_builder.build()`
         (simulator.py:264-267)."""
-        native.check(self.L.mg_refresh_maps(self._h, int(bool(force)), self._stream()))
+        self._check(self.L.mg_refresh_maps(self._h, int(bool(force)), self._stream()))
 
     def get_map(self, map_id: int) -> np.ndarray:
         """uint8 cell codes of slot `map_id` of a device-generated pool (host copy; synchronises the stream)."""
         out = np.zeros((self.map_height, self.map_width), np.uint8)
-        native.check(self.L.mg_get_map(self._h, int(map_id), _p(out, ct.c_uint8), self._stream()))
+        self._check(self.L.mg_get_map(self._h, int(map_id), _p(out, ct.c_uint8), self._stream()))
         return out
 
     def write_config_slot(self, slot: int, cfg) -> None:
@@ -202,7 +206,7 @@ class MettaGridBatch:
         if comp.agent_slot_names != self.compiled.agent_slot_names or comp.game_slot_names != self.compiled.game_slot_names:
             raise RuntimeError("mg_write_config_slot: the task's configuration differs from the handle's in the statistics layout")
         blob = np.ascontiguousarray(comp.blob, dtype=np.int32)
-        native.check(self.L.mg_write_config_slot(self._h, int(slot), _p(blob, ct.c_int32), blob.size, self._stream()))
+        self._check(self.L.mg_write_config_slot(self._h, int(slot), _p(blob, ct.c_int32), blob.size, self._stream()))
 
     def assign_map_configs(self, map_ids: Sequence[int], cfg_slots: Sequence[int]) -> None:
         """Map slot map_ids[i] plays configuration slot cfg_slots[i] from its next episode start on."""
@@ -210,25 +214,25 @@ class MettaGridBatch:
         c = np.ascontiguousarray(cfg_slots, dtype=np.int32)
         if m.shape != c.shape or m.ndim != 1:
             raise RuntimeError("map_ids and cfg_slots must be 1-D and of equal length")
-        native.check(self.L.mg_assign_map_configs(self._h, len(m), _p(m, ct.c_int32), _p(c, ct.c_int32), self._stream()))
+        self._check(self.L.mg_assign_map_configs(self._h, len(m), _p(m, ct.c_int32), _p(c, ct.c_int32), self._stream()))
 
     def set_map_max_steps(self, max_steps: Optional[Sequence[int]]) -> None:
         """Episode length per map of the pool (0 = the configuration's `max_steps`); None clears it.  The reference's
         evaluation suites give each map its own `game.max_steps` (recipes/experiment/navigation.py:32-59)."""
         if max_steps is None:
-            native.check(self.L.mg_set_map_max_steps(self._h, None))
+            self._check(self.L.mg_set_map_max_steps(self._h, None))
             self.map_max_steps = None
             return
         ms = np.ascontiguousarray(max_steps, dtype=np.int32)
         if ms.shape != (len(self.map_pool),):
             raise RuntimeError("max_steps must have one entry per map of the pool")
-        native.check(self.L.mg_set_map_max_steps(self._h, _p(ms, ct.c_int32)))
+        self._check(self.L.mg_set_map_max_steps(self._h, _p(ms, ct.c_int32)))
         self.map_max_steps = ms
 
     def env_map_dims(self, map_id: int) -> tuple[int, int]:
         """(height, width) of map `map_id` of the pool (reference: `MettaGrid.map_height / map_width`)."""
         h, w = ct.c_int32(), ct.c_int32()
-        native.check(self.L.mg_map_dims(self._h, int(map_id), ct.byref(h), ct.byref(w)))
+        self._check(self.L.mg_map_dims(self._h, int(map_id), ct.byref(h), ct.byref(w)))
         return int(h.value), int(w.value)
 
     def _stream(self) -> ct.c_void_p:
@@ -243,7 +247,7 @@ class MettaGridBatch:
         m = np.ascontiguousarray(base % len(self.map_pool) if map_ids is None else map_ids, dtype=np.int32)
         if s.shape != (n,) or m.shape != (n,):
             raise RuntimeError("seeds / map_ids must have one entry per environment being reset")
-        native.check(
+        self._check(
             self.L.mg_reset(self._h, None if ids is None else _p(ids, ct.c_int32), n, _p(s, ct.c_uint32), _p(m, ct.c_int32), self._stream())
         )
 
@@ -261,7 +265,7 @@ class MettaGridBatch:
             ):
                 if actions.numel() != self.actions.numel():
                     raise RuntimeError("actions has the wrong shape")
-                native.check(self.L.mg_step_actions(self._h, ct.c_void_p(actions.data_ptr()), self._stream()))
+                self._check(self.L.mg_step_actions(self._h, ct.c_void_p(actions.data_ptr()), self._stream()))
                 return
             t = torch.as_tensor(actions)
             if t.numel() != self.actions.numel():
@@ -271,44 +275,44 @@ class MettaGridBatch:
             if t.dtype not in (torch.int32, torch.int16, torch.int8, torch.uint8):
                 raise TypeError(f"Cannot cast actions from {t.dtype} to int32 according to the rule 'safe'")
             self.actions.copy_(t.reshape(-1).to(dtype=torch.int32), non_blocking=True)
-        native.check(self.L.mg_step(self._h, self._stream()))
+        self._check(self.L.mg_step(self._h, self._stream()))
 
     def step_path(self) -> str:
         """Names of the kernels one step launches for this configuration (diagnostic)."""
         return self.L.mg_step_path(self._h).decode()
 
     def set_auto_reset(self, enabled: bool, map_stride: int = 1) -> None:
-        native.check(self.L.mg_set_auto_reset(self._h, int(enabled), int(map_stride)))
+        self._check(self.L.mg_set_auto_reset(self._h, int(enabled), int(map_stride)))
         self.map_stride = int(map_stride)
 
     def set_early_reset(self, steps: Optional[Sequence[int]]) -> None:
         if steps is None:
-            native.check(self.L.mg_set_early_reset(self._h, None))
+            self._check(self.L.mg_set_early_reset(self._h, None))
         else:
             s = np.ascontiguousarray(steps, dtype=np.uint32)
             assert s.shape == (self.num_envs,)
-            native.check(self.L.mg_set_early_reset(self._h, _p(s, ct.c_uint32)))
+            self._check(self.L.mg_set_early_reset(self._h, _p(s, ct.c_uint32)))
 
     def end_episode(self, env: int = -1) -> None:
-        native.check(self.L.mg_end_episode(self._h, int(env), self._stream()))
+        self._check(self.L.mg_end_episode(self._h, int(env), self._stream()))
 
     def set_profiling(self, enabled, stride: int = 1) -> None:
         """False/0 off, True/1 time whole steps, 2 time the observation kernel only (HIP events on the launch stream).
         `stride`: record every stride-th step only (the event pair costs about 7 % of a 90 us step)."""
-        native.check(self.L.mg_set_profiling_stride(self._h, int(stride)))
-        native.check(self.L.mg_set_profiling(self._h, int(enabled)))
+        self._check(self.L.mg_set_profiling_stride(self._h, int(stride)))
+        self._check(self.L.mg_set_profiling(self._h, int(enabled)))
 
     def profile_read(self, max_steps: int = 4096) -> np.ndarray:
         """Per-step kernel durations (ms) recorded since profiling was enabled / last read."""
         ms = np.zeros(max_steps, np.float32)
         n = ct.c_int()
-        native.check(self.L.mg_profile_read(self._h, _p(ms, ct.c_float), max_steps, ct.byref(n)))
+        self._check(self.L.mg_profile_read(self._h, _p(ms, ct.c_float), max_steps, ct.byref(n)))
         return ms[: n.value].copy()
 
     # ---- inspection ------------------------------------------------------------------------------------------
     def env_info(self, env: int) -> dict:
         step, mid, seed, eps = ct.c_uint32(), ct.c_int32(), ct.c_uint32(), ct.c_uint32()
-        native.check(
+        self._check(
             self.L.mg_env_info(self._h, env, ct.byref(step), ct.byref(mid), ct.byref(seed), ct.byref(eps), self._stream())
         )
         return {"current_step": step.value, "map_id": mid.value, "seed": seed.value, "episodes": eps.value}
@@ -316,13 +320,13 @@ class MettaGridBatch:
     def env_table(self) -> np.ndarray:
         """u32 [E, 8]: current_step, rng index, seed, map_id, episodes, early_reset, done, error."""
         out = np.zeros((self.num_envs, 8), np.uint32)
-        native.check(self.L.mg_env_table(self._h, _p(out, ct.c_uint32), self._stream()))
+        self._check(self.L.mg_env_table(self._h, _p(out, ct.c_uint32), self._stream()))
         return out
 
     def finished_rewards(self, env: int):
         r = np.zeros(self.num_agents, np.float32)
         steps = ct.c_uint32()
-        native.check(self.L.mg_finished_rewards(self._h, env, _p(r, ct.c_float), ct.byref(steps), self._stream()))
+        self._check(self.L.mg_finished_rewards(self._h, env, _p(r, ct.c_float), ct.byref(steps), self._stream()))
         return r, int(steps.value)
 
     def current_step(self, env: int) -> int:
@@ -332,7 +336,7 @@ class MettaGridBatch:
         A, Sa, Sg = self.num_agents, len(self.compiled.agent_slot_names[0]), len(self.compiled.game_slot_names)
         av, at = np.zeros((A, Sa), np.float32), np.zeros((A, Sa), np.uint8)
         gv, gt = np.zeros(Sg, np.float32), np.zeros(Sg, np.uint8)
-        native.check(
+        self._check(
             self.L.mg_episode_stats(
                 self._h, env, int(last_finished), _p(av, ct.c_float), _p(at, ct.c_uint8), _p(gv, ct.c_float),
                 _p(gt, ct.c_uint8), self._stream(),
@@ -356,7 +360,7 @@ class MettaGridBatch:
     def agent_state(self, env: int) -> np.ndarray:
         R = len(self.compiled.resource_names)
         out = np.zeros((self.num_agents, 9 + 2 * R), np.int32)
-        native.check(self.L.mg_agent_state(self._h, env, _p(out, ct.c_int32), self._stream()))
+        self._check(self.L.mg_agent_state(self._h, env, _p(out, ct.c_int32), self._stream()))
         return out
 
     def assembler_state(self, env: int) -> np.ndarray:
@@ -365,17 +369,17 @@ class MettaGridBatch:
             raise RuntimeError("mg_num_assemblers failed")
         out = np.zeros((max(n, 1), 8), np.int32)
         if n:
-            native.check(self.L.mg_assembler_state(self._h, env, _p(out, ct.c_int32), self._stream()))
+            self._check(self.L.mg_assembler_state(self._h, env, _p(out, ct.c_int32), self._stream()))
         return out[:n]
 
     def chest_state(self, env: int) -> np.ndarray:
         """[n][5 + 2R]: r, c, chest config index, object id, n_items, (item, amount) in inventory order."""
         n = ct.c_int32()
-        native.check(self.L.mg_chest_state(self._h, env, None, 0, ct.byref(n), self._stream()))
+        self._check(self.L.mg_chest_state(self._h, env, None, 0, ct.byref(n), self._stream()))
         R = len(self.compiled.resource_names)
         out = np.zeros((max(n.value, 1), 5 + 2 * R), np.int32)
         if n.value:
-            native.check(self.L.mg_chest_state(self._h, env, _p(out, ct.c_int32), n.value, ct.byref(n), self._stream()))
+            self._check(self.L.mg_chest_state(self._h, env, _p(out, ct.c_int32), n.value, ct.byref(n), self._stream()))
         return out[: n.value]
 
     def grid_objects(self, env: int, min_row: int = -1, max_row: int = -1, min_col: int = -1, max_col: int = -1,
@@ -393,7 +397,7 @@ class MettaGridBatch:
         asm = self.assembler_state(env)
         chs = self.chest_state(env)
         rew = np.zeros(self.num_agents, np.float32)
-        native.check(self.L.mg_agent_stat_reward(self._h, env, _p(rew, ct.c_float), self._stream()))
+        self._check(self.L.mg_agent_stat_reward(self._h, env, _p(rew, ct.c_float), self._stream()))
         step = self.current_step(env)
         groups = self.agent_groups(env)
         use_bounds = min_row >= 0 and max_row >= 0 and min_col >= 0 and max_col >= 0
@@ -460,13 +464,13 @@ class MettaGridBatch:
         keys = order_from_pydict(list(inventory.keys()))
         items = np.asarray(keys, dtype=np.int32)
         amts = np.asarray([inventory[k] for k in keys], dtype=np.int32)
-        native.check(
+        self._check(
             self.L.mg_set_inventory(self._h, env, agent, len(keys), _p(items, ct.c_int32), _p(amts, ct.c_int32), self._stream())
         )
 
     def finished_summary(self, clear: bool = True) -> np.ndarray:
         out = np.zeros(3 + len(self.compiled.game_slot_names), np.float64)
-        native.check(self.L.mg_finished_summary(self._h, _p(out, ct.c_double), int(clear), self._stream()))
+        self._check(self.L.mg_finished_summary(self._h, _p(out, ct.c_double), int(clear), self._stream()))
         return out
 
     def dlpack(self, name: str):
@@ -484,7 +488,7 @@ class MettaGridBatch:
         """The finished-episode accumulator vector as a torch float64 tensor aliasing HBM (see finished_summary):
         `s = t.clone(); t.zero_(); dist.all_reduce(s)` keeps the multi-GPU exchange on the stream."""
         ptr, n = ct.POINTER(ct.c_double)(), ct.c_int32()
-        native.check(self.L.mg_summary_buffer(self._h, ct.byref(ptr), ct.byref(n)))
+        self._check(self.L.mg_summary_buffer(self._h, ct.byref(ptr), ct.byref(n)))
         addr = ct.cast(ptr, ct.c_void_p).value
         return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<f8", self._owner), device=self.device)
 
@@ -492,14 +496,14 @@ class MettaGridBatch:
         """u32[4] in HBM as a torch int32 tensor: [0] OR of every environment's error bits (sticky), [1] episodes
         finished since creation.  Reading it needs no per-environment copy; `check_errors` is the raising form."""
         ptr, n = ct.POINTER(ct.c_uint32)(), ct.c_int32()
-        native.check(self.L.mg_status_buffer(self._h, ct.byref(ptr), ct.byref(n)))
+        self._check(self.L.mg_status_buffer(self._h, ct.byref(ptr), ct.byref(n)))
         addr = ct.cast(ptr, ct.c_void_p).value
         return self._torch.as_tensor(_DevArray(addr, (int(n.value),), "<i4", self._owner), device=self.device)
 
     def check_errors(self) -> None:
         """Raise RuntimeError if any environment flagged an internal error (the reference's core throws out of
         `step()`; here the flag is raised on the device and surfaces at the caller's next synchronisation point)."""
-        native.check(self.L.mg_check_errors(self._h, self._stream()))
+        self._check(self.L.mg_check_errors(self._h, self._stream()))
 
     def close(self) -> None:
         """Free the handle's HBM now.  Every tensor this object handed out (`observations`, `rewards`, ...,

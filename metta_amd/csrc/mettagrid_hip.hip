@@ -201,7 +201,9 @@ static bool mg_has_damage(const MgConfig& c) {
 }
 
 static int mg_check_supported(const MgConfig& c, const char* who) {
-  if (c.R > MGD_MAX_R) return fail(std::string(who) + ": more than 16 resources are not supported on the device path yet");
+  if (c.R > MGD_MAX_R)
+    return fail(std::string(who) + ": " + std::to_string(c.R) + " resources, this build of the library holds " + std::to_string(MGD_MAX_R) +
+                (MGD_MAX_R < 32 ? " (load the wide-inventory build libmettagrid_hip_r32.so: up to 32)" : " (the device path's ceiling)"));
   if (c.A > 8191) return fail(std::string(who) + ": too many agents per environment");
   for (const auto& a : c.assemblers)
     for (const auto& p : a.protocols)
@@ -253,7 +255,8 @@ static int dalloc(mg_handle* h, T** p, size_t n, bool map_alloc = false) {
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return "mettagrid_hip 0.1 (gfx950; blob v" "4" ")"; }
+const char* mg_version(void) { return MGD_MAX_R == 16 ? "mettagrid_hip 0.1 (gfx950; blob v4; 16 resources)" : "mettagrid_hip 0.1 (gfx950; blob v4; 32 resources)"; }
+int mg_max_resources(void) { return MGD_MAX_R; }
 
 int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int device_id, mg_handle** out) {
   if (!out) return fail("mg_create: out is NULL");

@@ -43,7 +43,14 @@ enum MgAr {
 enum MgPr { PR_MIN_AGENTS = 0, PR_COOLDOWN, PR_OFF_VIBES, PR_OFF_IN, PR_OFF_OUT, PR_OFF_IN_S, PR_OFF_OUT_S, PR_WORDS };
 
 #define MG_SR_WORDS 7  // stat-reward entry: agent slot, game slot, weight, has_max, max, collective constant, aligned flag
-#define MGD_MAX_R 16  // device inventories hold up to 16 resources (uint16 amounts + 16-entry order list)
+// Device inventories hold up to MGD_MAX_R resources (uint16 amounts + an order list of that many entries, in the agent
+// record).  The library is built twice: libmettagrid_hip.so with 16 (112-byte records: the arena / navigation / CvC
+// resource sets) and libmettagrid_hip_r32.so with 32 (160-byte records) for wider resource lists; 32-bit masks over
+// the resources (dirty amounts, diversity presence, pending chest amounts) set the ceiling.
+#ifndef MGD_MAX_R
+#define MGD_MAX_R 16
+#endif
+static_assert(MGD_MAX_R == 16 || MGD_MAX_R == 32, "MGD_MAX_R: 16 or 32");
 
 struct MgDcBuilder {
   std::vector<int32_t> w;
@@ -172,9 +179,9 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
         for (size_t i = 0; i < rr.size(); i++) b.w[(size_t)o + 1 + i] = rr[i];
         rec[GR_OFF_REGEN] = o;
       }
-      int32_t dm = 0;
-      for (int32_t r : g.diversity) dm |= (1 << r);
-      rec[GR_DIVERSITY_MASK] = dm;
+      uint32_t dm = 0;
+      for (int32_t r : g.diversity) dm |= (1u << r);
+      rec[GR_DIVERSITY_MASK] = (int32_t)dm;
       rec[GR_OFF_DMG_THRESHOLD] = b.put_kv(g.damage_threshold);
       rec[GR_OFF_DMG_RESOURCES] = b.put_kv(g.damage_resources);
       int o = b.reserve(GR_WORDS);

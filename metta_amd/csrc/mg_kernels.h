@@ -106,9 +106,9 @@ struct Lds {
   uint16_t* grid;
   DAgent* ag;
   DAgent* ch;       // chest records (directly after the agent records)
-  int* gsetv;       // [16] pending chest.<r>.amount values; gsetm[0] = which
+  int* gsetv;       // [MGD_MAX_R] pending chest.<r>.amount values; gsetm[0] = which
   uint32_t* gsetm;
-  unsigned long long* gset64;  // [16] the same as sequence-keyed maxima (parallel action rounds), or null
+  unsigned long long* gset64;  // [MGD_MAX_R] the same as sequence-keyed maxima (parallel action rounds), or null
   DAsm* as;
   int* gd;
   uint32_t* dirty_amt;
@@ -175,7 +175,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->tmp = (int*)(base + tmpo);
   }
   size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
-  size_t gsv = take(16 * 4 + 16);
+  size_t gsv = take(MGD_MAX_R * 4 + 16);
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4);
   size_t ord = take((size_t)A * 2), ex = take((size_t)A * 4), ta = take((size_t)A * 4), win = take((size_t)NWIN * 4);
   size_t mtn = take(624 * 4), tk = take(16), fl = take(16), rows = take((size_t)ROWB * nwaves);
@@ -185,7 +185,7 @@ __host__ __device__ inline size_t mg_carve(unsigned char* base, Lds* l, int HW, 
     l->ocnt = (uint32_t*)(base + oc) + 1; l->heap = (uint16_t*)(base + hp); l->pat = (uint32_t*)(base + pt);
     l->ainfo = (int4*)(base + ai);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->as = (DAsm*)(base + as);
-    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + 64); l->gset64 = nullptr;
+    l->ch = l->ag + a_rec; l->gsetv = (int*)(base + gsv); l->gsetm = (uint32_t*)(base + gsv + MGD_MAX_R * 4); l->gset64 = nullptr;
     l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
     l->order = (uint16_t*)(base + ord); l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta);
     l->win = (uint32_t*)(base + win); l->mtnext = (uint32_t*)(base + mtn); l->tokacc = (float*)(base + tk);

@@ -48,7 +48,7 @@ struct __align__(16) DAgent {  // 112 bytes; one per agent, [E][A] in HBM, stage
   uint16_t amt[MGD_MAX_R];
   uint8_t order[MGD_MAX_R];  // unordered_map iteration order of the inventory
   uint8_t n_items, nb, next_resize, diversity;
-  uint16_t presence, pad;
+  uint32_t presence;  // diversity-tracked resources currently held (bit per resource)
   // Hot per-step counters live in the record (it is streamed every step anyway) instead of the stat array:
   // action.<noop|move|change_vibe>.success / .failed; action.failed is their sum; max_swm above.
   // mg_episode_stats merges them back into the reference's key set.
@@ -56,7 +56,7 @@ struct __align__(16) DAgent {  // 112 bytes; one per agent, [E][A] in HBM, stage
   float aligned;  // the collective's "aligned.agent" statistic: its members on this map (constant over an episode)
   uint32_t pad2;
 };
-static_assert(sizeof(DAgent) == 112, "DAgent layout");
+static_assert(sizeof(DAgent) == (MGD_MAX_R == 16 ? 112 : 160), "DAgent layout");
 
 struct __align__(16) DAsm {  // assembler.hpp:245-259
   uint32_t cooldown_end, cooldown_duration, uses_count, clipped;
@@ -148,15 +148,30 @@ __device__ inline void mg_insert_node(DAgent* a, int k) {
   a->n_items = (uint8_t)(n + 1);
 }
 __device__ inline void mg_rehash(DAgent* a, int m) {
-  unsigned long long o0 = 0, o1 = 0;  // the 16-entry order list, packed (no private array -> no scratch)
+  // the order list, packed eight entries per register (no private array -> no scratch)
+  unsigned long long o0 = 0, o1 = 0;
+#if MGD_MAX_R > 16
+  unsigned long long o2 = 0, o3 = 0;
+#endif
   int n = a->n_items;
   for (int i = 0; i < n; i++) {
-    unsigned long long v = a->order[i];
-    if (i < 8) o0 |= v << (8 * i); else o1 |= v << (8 * (i - 8));
+    unsigned long long v = (unsigned long long)a->order[i] << (8 * (i & 7));
+    if (i < 8) o0 |= v;
+    else if (i < 16) o1 |= v;
+#if MGD_MAX_R > 16
+    else if (i < 24) o2 |= v;
+    else o3 |= v;
+#endif
   }
   a->n_items = 0;
   a->nb = (uint8_t)m;
-  for (int i = 0; i < n; i++) mg_insert_node(a, (int)(((i < 8 ? o0 >> (8 * i) : o1 >> (8 * (i - 8)))) & 0xFF));
+  for (int i = 0; i < n; i++) {
+    unsigned long long w = i < 8 ? o0 : o1;
+#if MGD_MAX_R > 16
+    if (i >= 16) w = i < 24 ? o2 : o3;
+#endif
+    mg_insert_node(a, (int)((w >> (8 * (i & 7))) & 0xFF));
+  }
 }
 __device__ inline void mg_map_insert(DAgent* a, int k) {  // operator[] on an absent key
   int n_elt = a->n_items;
@@ -238,10 +253,10 @@ __device__ inline void mg_on_change(Ctx& cx, int ai, int item, int delta) {
     mg_stat_add(cx, ai, cx.AS.lost(item), -delta);
   cx.dirty_amt[ai] |= (1u << item);
   const int* gr = group_rec(cx.dc, a->group);
-  if (gr[GR_DIVERSITY_MASK] & (1 << item)) {
+  if ((uint32_t)gr[GR_DIVERSITY_MASK] & (1u << item)) {
     bool had = (a->presence >> item) & 1, has = a->amt[item] > 0;
     if (had != has) {
-      a->presence = (uint16_t)(a->presence ^ (1u << item));
+      a->presence = a->presence ^ (1u << item);
       a->diversity = (uint8_t)(a->diversity + (has ? 1 : -1));
       cx.dirty_misc[ai] |= 1u;
     }

@@ -12,7 +12,11 @@ from pathlib import Path
 
 # METTA_AMD_LIB: another build of the same library (kernel experiments, tools/variants.sh)
 _LIB_PATH = Path(os.environ.get("METTA_AMD_LIB") or Path(__file__).resolve().parent / "libmettagrid_hip.so")
+# the wide-inventory build of the same sources (-DMGD_MAX_R=32): resource lists of 17..32 names
+_LIB_PATH_WIDE = Path(__file__).resolve().parent / "libmettagrid_hip_r32.so"
+NARROW_MAX_RESOURCES, WIDE_MAX_RESOURCES = 16, 32
 _lib = None
+_lib_wide = None
 
 
 class MgBuffers(ct.Structure):
@@ -44,6 +48,7 @@ _vp, _i32p, _u32p, _u8p, _f32p, _f64p = (
 SYMBOLS = {
     "mg_last_error": (ct.c_char_p, []),
     "mg_version": (ct.c_char_p, []),
+    "mg_max_resources": (ct.c_int, []),
     "mg_create": (ct.c_int, [_i32p, ct.c_size_t, ct.c_int, ct.c_int, ct.POINTER(_vp)]),
     "mg_set_maps": (ct.c_int, [_vp, _u8p, ct.c_int, ct.c_int, ct.c_int]),
     "mg_set_maps_ragged": (ct.c_int, [_vp, _u8p, ct.c_int, _i32p, _i32p]),
@@ -92,33 +97,44 @@ SYMBOLS = {
 }
 
 
-def lib_path() -> Path:
-    return _LIB_PATH
+def lib_path(wide: bool = False) -> Path:
+    return _LIB_PATH_WIDE if wide else _LIB_PATH
 
 
-def load() -> ct.CDLL:
-    """Load the HIP library (built in-tree by `__graft_entry__.build()` / metta_amd/csrc/Makefile)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not _LIB_PATH.exists():
+def load(wide: bool = False) -> ct.CDLL:
+    """Load the HIP library (built in-tree by `__graft_entry__.build()` / metta_amd/csrc/Makefile).  `wide`: the
+    32-resource build."""
+    global _lib, _lib_wide
+    have = _lib_wide if wide else _lib
+    if have is not None:
+        return have
+    path = lib_path(wide)
+    if not path.exists():
         raise ImportError(
-            f"{_LIB_PATH} is missing: build it with `make -C metta_amd/csrc` (hipcc --offload-arch=gfx950). "
+            f"{path} is missing: build it with `make -C metta_amd/csrc` (hipcc --offload-arch=gfx950). "
             "The device path has no CPU fallback."
         )
     # torch ships its own libamdhip64: it must be the process's HIP runtime (tensors are exchanged by pointer), so
     # it is loaded first and this library binds to the same one by soname
     import torch  # noqa: F401
 
-    L = ct.CDLL(str(_LIB_PATH))
+    L = ct.CDLL(str(path))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = L
+    if wide:
+        _lib_wide = L
+    else:
+        _lib = L
     return L
 
 
-def check(rc: int) -> None:
+def load_for(num_resources: int) -> ct.CDLL:
+    """The build whose inventories hold `num_resources` (more than 32: the narrow one, whose mg_create says why not)."""
+    return load(wide=NARROW_MAX_RESOURCES < num_resources <= WIDE_MAX_RESOURCES)
+
+
+def check(rc: int, L: ct.CDLL | None = None) -> None:
     if rc != 0:
-        raise RuntimeError(load().mg_last_error().decode())
+        raise RuntimeError((L or load()).mg_last_error().decode())

@@ -29,7 +29,8 @@ sys.path.insert(0, str(ROOT))
 
 from oracle.gen_golden import GOLD, digest, encode_names, install_reference_shims  # noqa: E402
 
-SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115]
+SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117]
+WIDE_SEEDS = {116: 24, 117: 32}  # resource lists beyond 16: one team starts with every resource (map growth 13 -> 29 -> 59)
 COLLECTIVE_SEEDS = {113, 114, 115}  # + collectives: membership by tag, stat rewards on the collective's statistics
 STEPS = 200
 
@@ -49,6 +50,7 @@ def features_of(game) -> dict:
         "chest_search": any(a.chest_search_distance > 0 for a in asm),
         "move_costs": bool(game.actions.move.consumed_resources),
         "collectives": bool(game.collectives) and any("aligned.agent" in a.rewards.stats for a in game.agents),
+        "wide_resources": len(game.resource_names) > 16,
         "token_base": int(game.obs.token_value_base),
     }
 
@@ -65,8 +67,12 @@ def main() -> None:
 
     covered: dict[str, int] = {}
     for seed in SEEDS:
-        cfg = rand_cfg(np.random.RandomState(seed), device_safe=True, collectives=seed in COLLECTIVE_SEEDS)
+        cfg = rand_cfg(np.random.RandomState(seed), device_safe=True, collectives=seed in COLLECTIVE_SEEDS,
+                       num_resources=WIDE_SEEDS.get(seed, 0))
         game = cfg.game
+        if seed in WIDE_SEEDS:
+            game.agents[0].inventory.initial = {r: int(1 + (i * 7) % 11) for i, r in enumerate(game.resource_names)}
+            game.agents[0].inventory.default_limit = 65535
         grid = np.asarray(game.map_builder.build(np.random.default_rng(seed)))
         dump = game.model_dump(mode="json", exclude={"map_builder"})
         ref_game = RefGameConfig.model_validate(dump)  # the reference's schema accepts (and re-defaults) our dump
@@ -109,7 +115,7 @@ def main() -> None:
         print(f"wrote feature_{seed}.npz", {k: v for k, v in feats.items() if v})
     print("feature coverage over the fixture set:", covered)
     need = ["attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
-            "limit_modifiers", "chest_search", "collectives"]
+            "limit_modifiers", "chest_search", "collectives", "wide_resources"]
     missing = [k for k in need if not covered.get(k)]
     assert not missing, f"no fixture exercises {missing}: extend SEEDS"
 

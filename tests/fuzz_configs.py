@@ -81,8 +81,11 @@ def add_collectives(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGri
     return cfg
 
 
-def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: bool = False) -> MettaGridConfig:
+def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: bool = False,
+             num_resources: int = 0) -> MettaGridConfig:  # fmt: skip
     R = RES[: rs.randint(3, len(RES) + 1)]
+    if num_resources:  # wide resource lists (17..32: the wide-inventory build of the library)
+        R = (RES + [f"res{i}" for i in range(num_resources)])[:num_resources]
 
     def rr():
         return R[rs.randint(len(R))]

@@ -30,6 +30,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} is declared in include/mettagrid_hip.h but not exported"
     assert set(native.SYMBOLS) == set(declared), "metta_amd/native.py binds a different symbol set than the header"
     assert b"gfx950" in L.mg_version()
+    assert L.mg_max_resources() == 16
+    # the wide-inventory build (17..32 resources) exports the same C-ABI
+    W = native.load(wide=True)
+    for name in declared:
+        assert hasattr(W, name), f"{name} missing from libmettagrid_hip_r32.so"
+    assert W.mg_max_resources() == 32 and native.load_for(20) is W and native.load_for(16) is L and native.load_for(40) is L
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -163,7 +163,52 @@ def test_golden_arena(name):
     b.close()
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115])
+@pytest.mark.parametrize("seed,num_resources", [(s, r) for r in (17, 24, 32) for s in range(200 + r, 204 + r)])
+def test_fuzz_wide_resource_lists_vs_oracle(seed, num_resources):
+    """17..32 resources: the wide-inventory build (libmettagrid_hip_r32.so, 160-byte agent records).  One team starts
+    with every resource, so the inventory's unordered_map emulation grows through 13 -> 29 -> 59 buckets."""
+    from metta_amd import native
+
+    rs = np.random.RandomState(seed)
+    cfg = rand_cfg(rs, device_safe=True, num_resources=num_resources, collectives=bool(seed % 2))
+    game = cfg.game
+    full = game.agents[0]
+    full.inventory.initial = {r: int(1 + (i * 7) % 11) for i, r in enumerate(game.resource_names)}
+    full.inventory.default_limit = 65535
+    maps = [game.map_builder.build(np.random.default_rng(77 * seed + i)) for i in range(2)]
+    E, A = 3, game.num_agents
+    seeds = [seed * 10 + e for e in range(E)]
+    map_ids = [e % 2 for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, map_ids)
+    assert b.L is native.load(wide=True) and b.L.mg_max_resources() == 32
+    b.set_auto_reset(False)
+    comp, oras = _oracles(cfg, maps, seeds, map_ids)
+    nA = len(comp.action_names)
+    _compare_step(b, oras, 0, A)
+    for t in range(1, 121):
+        acts = np.stack([fuzz_actions(rs, game, nA) for _ in range(E)])
+        if rs.randint(20) == 0:
+            e, ag = int(rs.randint(E)), int(rs.randint(A))
+            inv = {int(rs.randint(num_resources)): int(rs.randint(0, 400)) for _ in range(rs.randint(0, 24))}
+            b.set_inventory(e, ag, inv)
+            oras[e].set_inventory(ag, inv)
+        b.step(acts.reshape(-1))
+        for e, o in enumerate(oras):
+            o.step(acts[e])
+        _compare_step(b, oras, t, A)
+        if t % 40 == 0:
+            _compare_state(b, oras, t)
+    b.close()
+
+
+def test_more_resources_than_the_wide_build_holds_is_an_error():
+    cfg = rand_cfg(np.random.RandomState(1), device_safe=True, num_resources=33)
+    maps = [cfg.game.map_builder.build(np.random.default_rng(1))]
+    with pytest.raises(RuntimeError, match="33 resources, this build of the library holds 16"):
+        _batch(cfg, maps, 1, [1], [0])
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117])
 def test_golden_feature_families(seed):
     """tests/golden/feature_<seed>.npz: configurations with attack / armor / loot / freeze, transfer, chests, damage,
     regeneration, partial usage ... converted by the reference's REAL `convert_to_cpp_game_config` and stepped by its

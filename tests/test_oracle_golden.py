@@ -112,7 +112,7 @@ def test_bridge_matches_reference_python_converter_shapes():
     assert comp.object_type_names[0] == "agent" and comp.object_type_names[1:] == sorted(cfg.game.objects.keys())
 
 
-FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115]
+FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117]
 
 
 def load_feature_fixture(seed):
