@@ -387,8 +387,9 @@ class MettaGridBatch:
         """`MettaGrid::grid_objects` (BIND/mettagrid_c.cpp:754-918) of one environment: {object id: dict}.
 
         Holds the identity, position, inventory and the agent / assembler / chest state fields of the reference's
-        dicts.  Not reproduced: the injected per-feature observation values (`tag`, `protocol_input:*`, ...) and the
-        assembler's protocol listings (`current_protocol_*`, `protocols`) -- they restate the configuration."""
+        dicts, and an assembler's `protocols` listing in the reference's order.  Not reproduced: the injected
+        per-feature observation values (`tag`, `protocol_input:*`, ...) and `current_protocol_*` (they restate the
+        configuration and the observation tokens)."""
         c = self.compiled
         game = self.cfg.game if hasattr(self.cfg, "game") else None
         mid = self.env_info(env)["map_id"]
@@ -446,6 +447,7 @@ class MettaGridBatch:
                         uses_count=int(np.uint32(a[7])),
                         max_uses=int(getattr(ocfg, "max_uses", 0)),
                         allow_partial_usage=bool(getattr(ocfg, "allow_partial_usage", False)),
+                        protocols=[dict(p) for p in (c.assembler_protocol_listing or {}).get(c.cell_names[code - 1], [])],
                     )
                 elif kind == 4:  # chest
                     ch = chs[n_chest]

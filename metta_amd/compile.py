@@ -101,6 +101,7 @@ class CompiledGame:
     agent_slot_names: list[list[str]]  # per group
     game_slot_names: list[str]
     extra: dict[str, Any] = field(default_factory=dict)
+    assembler_protocol_listing: dict = field(default_factory=dict)  # assembler object name -> `protocols` of grid_objects
 
     @property
     def cell_code(self) -> dict[str, int]:
@@ -443,6 +444,7 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     for o in walls:
         w.i(type_id[key_of[id(o)]], o.vibe)
         w.list([tag_id[t] for t in o.tags])
+    assembler_protocol_listing: dict[str, list] = {}
     w.i(len(assemblers))
     for o in assemblers:
         w.i(type_id[key_of[id(o)]], o.vibe, int(o.allow_partial_usage), o.max_uses, int(o.clip_immune),
@@ -481,6 +483,16 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
             plist = sorted(plist, key=lambda pi: -protos[pi][0])
             w.i(key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF)
             w.list(plist)
+        # the listing `MettaGrid::grid_objects` gives (mettagrid_c.cpp:864-893): the protocol map's iteration order
+        # (assembler.hpp:334-349: operator[] inserts in list order, identity hash on the 64-bit key), each key's
+        # protocols by descending min_agents
+        listing = []
+        for key in order_from_inserts(list(keymap.keys())):
+            for pi in sorted(keymap[key], key=lambda pi: -protos[pi][0]):
+                min_agents, cooldown, vids, ins, outs = protos[pi]
+                listing.append({"inputs": dict(ins), "outputs": dict(outs), "cooldown": cooldown,
+                                "min_agents": min_agents, "vibes": list(vids)})  # fmt: skip
+        assembler_protocol_listing[key_of[id(o)]] = listing
     w.i(len(chests))
     for o in chests:
         w.i(type_id[key_of[id(o)]], o.vibe)
@@ -507,7 +519,8 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     w.i(len(agent_slot_names[0]) if agent_slot_names else 0, len(game_slot_names))
     w.i(MG_BLOB_MAGIC)
 
-    object_type_names = [""] * (len(type_names_sorted) + 1)
+    # mettagrid_c.cpp:163-177: sized by the number of cell entries (agent cells included), grown to the largest type id
+    object_type_names = [""] * max(len(type_names_sorted) + 1, len(cell_names))
     object_type_names[0] = "agent"
     for n, i in type_id.items():
         object_type_names[i] = n
@@ -528,6 +541,7 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
         group_names=group_names,
         tag_names=tag_names,
         object_type_names=object_type_names,
+        assembler_protocol_listing=assembler_protocol_listing,
         feature_names={f.id: f.name for f in feats},
         agent_slot_names=agent_slot_names,
         game_slot_names=game_slot_names,

@@ -109,7 +109,8 @@ def test_bridge_matches_reference_python_converter_shapes():
     assert f["agent:group"] == 0 and f["remaining_uses"] == 11 and f["inv:ore_red"] == 12 and f["inv:ore_red:p1"] == 13
     assert len(comp.feature_names) == 12 + 2 * 10 + 2 * 10  # 52 feature ids
     assert comp.tag_names == ["agent", "armory", "assembler", "generator_red", "lasery", "mine_red", "wall"]
-    assert comp.object_type_names[0] == "agent" and comp.object_type_names[1:] == sorted(cfg.game.objects.keys())
+    # (mettagrid_c.cpp:163-177: one entry per cell name, so three empty names follow the six object types)
+    assert comp.object_type_names == ["agent"] + sorted(cfg.game.objects.keys()) + ["", "", ""]
 
 
 FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117]
