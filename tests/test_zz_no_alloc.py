@@ -2,9 +2,10 @@
 
 Called through the C-ABI and checked, bit for bit, against the existing entry point on twin handles (same config,
 maps, seeds, actions): two runs in a row, the second with a smaller input (fewer environments), so that whatever the
-first run left in the GPU's static scratch array is still there when the second starts.  Covers both step paths: the
-wave-parallel fast path (arena: mode words + pending assembler uses + executed actions go through the scratch) and
-the general path (combat: executed actions).  Collected last (the round's end runs pytest -x).
+first run left in the GPU's static scratch array is still there when the second starts.  Covers the three step paths:
+the fused one-launch step (arena: its hand-overs live in LDS, the scratch stays idle and the entry point must still
+agree), the three-launch fast path (`MG_NO_FUSED=1`: mode words + pending assembler uses + executed actions go through
+the scratch) and the general path (combat: executed actions).  Collected last (the round's end runs pytest -x).
 """
 
 import ctypes as ct
@@ -57,6 +58,15 @@ def test_noalloc_step_matches_mg_step_fast_path():
     maps = load_map_pool()[:8]
     _twin_run(cfg, maps, 96, 100, 5, seed=5)
     _twin_run(cfg, maps, 7, 100, 5, seed=9)  # smaller input, right after the larger one
+
+
+def test_noalloc_step_matches_mg_step_three_launch_fast_path(monkeypatch):
+    monkeypatch.setenv("MG_NO_FUSED", "1")  # read by mg_set_maps: act_fast -> uses -> obs, hand-overs in the scratch
+    cfg = make_arena(24)
+    cfg.game.max_steps = 40
+    maps = load_map_pool()[:8]
+    _twin_run(cfg, maps, 64, 80, 5, seed=15)
+    _twin_run(cfg, maps, 5, 80, 5, seed=19)
 
 
 def test_noalloc_step_matches_mg_step_general_path():
