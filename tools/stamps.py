@@ -14,7 +14,15 @@ native.check(b.L.mg_debug_stamps(b._h, None, 1))
 b.step(tab[0]); torch.cuda.synchronize()
 out=np.zeros((E,16),np.uint64)
 native.check(b.L.mg_debug_stamps(b._h, out.ctypes.data_as(ct.POINTER(ct.c_uint64)), 1))
+ok = out[:,0] != 0
+print("blocks with stamps:", int(ok.sum()), "of", E)
+out = out[ok]
+E = int(ok.sum())
 t0=int(out[:,0].min())
+st = out[:,0].astype(np.int64)-t0; en = out[:,6].astype(np.int64)-t0
+print("start offset percentiles [1,10,50,90,99,100]:", np.percentile(st,[1,10,50,90,99,100]))
+print("end offset percentiles   [1,10,50,90,99,100]:", np.percentile(en,[1,10,50,90,99,100]))
+print("per-block total percentiles [10,50,90,99,100]:", np.percentile(en-st,[10,50,90,99,100]))
 print("start offsets (first/second wave of workgroups): median", np.median(out[:,0].astype(np.int64)-t0), "p90", np.percentile(out[:,0].astype(np.int64)-t0,90))
 print("uses/no-uses split of stage 2->3:", np.percentile(np.diff(out[:,2:4].astype(np.int64),axis=1),[10,50,90,99]))
 d=np.diff(out[:,:7].astype(np.int64),axis=1)
