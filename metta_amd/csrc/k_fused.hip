@@ -190,7 +190,18 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
   const CellCodec cc{a.NW, A, a.NAmax};
   const int skind = cc.kind(scell);
   const bool mover = is_move && inb && skind == MG_CELL_EMPTY;
-  const bool user = is_move && inb && skind == MG_CELL_ASSEMBLER;
+  const bool bump = is_move && inb && skind == MG_CELL_ASSEMBLER;
+  // A use of an assembler that is cooling down (without partial usage) or used up fails whatever happens earlier in
+  // this step (nothing in a step shortens a cooldown or lowers a use count; assembler.hpp:455-470) and has no effect
+  // but the failed move: decided here, lane-parallel, instead of queueing it for the serial use phase.  The record
+  // loads are issued now and consumed after the move fixed point.
+  DAsm bump_as = {0, 0, 0, 0};
+  int bump_cfg = 0;
+  if (bump) {
+    const int ai_ = cc.asm_idx(scell);
+    bump_as = l.as[ai_];
+    bump_cfg = l.ainfo[ai_].z;
+  }
   const uint32_t P = ((uint32_t)r << 16) | (uint32_t)c;
   const uint32_t Tm = mover ? (((uint32_t)tr << 16) | (uint32_t)tc) : 0xFFFFFFFFu;
 
@@ -215,6 +226,14 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
   }
 
   // ---- assembler uses, in rank order, with the ring as it stood at that moment ------------------------------
+  bool user = bump;
+  if (bump) {
+    const int* arec = asm_rec(dc, bump_cfg);
+    const uint32_t max_uses = (uint32_t)arec[AR_MAX_USES];
+    const bool used_up = max_uses > 0 && bump_as.uses_count >= max_uses;
+    const bool cooling = bump_as.cooldown_end > env.step && arec[AR_ALLOW_PARTIAL] == 0;
+    user = !(used_up || cooling);
+  }
   unsigned long long umask = __ballot(user);
   int n_pending = 0;
   uint8_t* pend = l.pend;
@@ -350,6 +369,11 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   const int max_round = l.flags[0];
+  if (a.dbg && lane == 0) {
+    a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 8] = (unsigned long long)count;
+    a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 9] = (unsigned long long)max_round;
+    a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 10] = 0;
+  }
   for (int rd = 0; rd <= max_round; rd++) {
     for (int q0 = 0; q0 < count; q0 += MG_FUSED_SLOTS) {
       const int q = q0 + lane;
@@ -366,6 +390,7 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
         }
         const bool ok = mg_assembler_use_core(cx, actor, asm_idx, near, vibes, nn);
         if (ok) {
+          if (a.dbg) atomicAdd(&a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 10], 1ull);
           l.ag[actor].succ[MG_ACT_MOVE] += 1;
           l.exec[actor] = act;
           l.succ[actor] = 1;
@@ -570,13 +595,19 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(2);
     const int n_uses = l.flags[3];
+#define MG_STAMPL(slot) do { if (a.dbg && wave == actor && lane == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + (slot)] = clock64(); } while (0)
     if (n_uses > 0) {  // block-uniform
       Ctx cx;
+      MG_STAMPL(11);
       mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
       cx.grid = nullptr;
+      MG_STAMPL(12);
       if (wave == actor) mg_fused_uses(a, l, cx, n_uses, lane);
+      MG_STAMPL(13);
       __syncthreads();
+      MG_STAMPL(14);
       mg_flush_stats(a, l, cx, e, tid, nt);
+      MG_STAMPL(15);
     }
     MG_STAMP(3);
   }

@@ -29,6 +29,7 @@ enum MgGr {
   GR_GROUP_ID = 0, GR_NAME_IDX, GR_FREEZE_DURATION, GR_INITIAL_VIBE, GR_OFF_TAGS, GR_N_LIMITS, GR_OFF_LIMITS,
   GR_OFF_LIMIT_OF, GR_OFF_MODIFIER, GR_OFF_LIMITS_ORDER, GR_OFF_INITIAL, GR_OFF_STAT_REWARDS, GR_OFF_GOAL,
   GR_OFF_REGEN, GR_DIVERSITY_MASK, GR_HAS_MODIFIERS, GR_OFF_DMG_THRESHOLD, GR_OFF_DMG_RESOURCES,
+  GR_OFF_LIMIT_MASK,  // per limit: bit r set = resource r counts against it (the inverse of GR_OFF_LIMIT_OF)
   GR_COLLECTIVE,  // the collective the group's agents end up in (last "collective:<name>" tag), or -1
   GR_WORDS
 };
@@ -144,6 +145,14 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
       for (const auto& kv : inv.limits_map_order)
         for (const auto& m : inv.limits[(size_t)kv.v].modifiers) { modifier[(size_t)m.k] = 1; has_mod = true; }
       { int o = b.reserve((int)limit_of.size()); for (size_t i = 0; i < limit_of.size(); i++) b.w[(size_t)o + i] = limit_of[i]; rec[GR_OFF_LIMIT_OF] = o; }
+      {
+        std::vector<int32_t> lmask(std::max<size_t>(inv.limits.size(), 1), 0);
+        for (size_t r = 0; r < limit_of.size(); r++)
+          if (limit_of[r] >= 0 && (size_t)limit_of[r] < lmask.size()) lmask[(size_t)limit_of[r]] |= (int32_t)(1u << r);
+        int o = b.reserve((int)lmask.size());
+        for (size_t i = 0; i < lmask.size(); i++) b.w[(size_t)o + i] = lmask[i];
+        rec[GR_OFF_LIMIT_MASK] = o;
+      }
       { int o = b.reserve((int)modifier.size()); for (size_t i = 0; i < modifier.size(); i++) b.w[(size_t)o + i] = modifier[i]; rec[GR_OFF_MODIFIER] = o; }
       rec[GR_HAS_MODIFIERS] = has_mod ? 1 : 0;
       rec[GR_OFF_LIMITS_ORDER] = b.put_kv(inv.limits_map_order);

@@ -216,9 +216,7 @@ __device__ inline int mg_effective_limit(const int* dc, const int* gr, const DAg
 // SharedInventoryLimit::amount == sum of the amounts of the resources mapped to the limit (mod 2^16)
 __device__ inline int mg_limit_sum(const int* dc, const int* gr, const DAgent* a, int li, int R) {
   int s = 0;
-  const int* lo = dc + gr[GR_OFF_LIMIT_OF];
-  for (int r = 0; r < R; r++)
-    if (lo[r] == li) s += a->amt[r];
+  for (uint32_t m = (uint32_t)dc[gr[GR_OFF_LIMIT_MASK] + li]; m; m &= m - 1) s += a->amt[__ffs(m) - 1];
   return s & 0xFFFF;
 }
 // Inventory::free_space (inventory.cpp:96-108)
@@ -333,6 +331,8 @@ __device__ inline int inv_update(Ctx& cx, int ai, int item, int delta, bool igno
 // bitmasks over list positions.
 __device__ inline int mg_shared_update(Ctx& cx, const int* list, int n, int item, int delta) {
   if (n == 0) return 0;
+  // one inventory: both branches of the algorithm below end in a single update by `delta` (clamped by the limits)
+  if (n == 1) return inv_update(cx, list[0], item, delta);
   uint32_t consider, next = (1u << n) - 1u;
   int delta_remaining = delta, num_remaining = n;
   int per = delta_remaining / num_remaining;
@@ -498,7 +498,10 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
     n_inputs = nn;
   }
   const int* dc = cx.dc;
-  DAsm* as = &cx.as[asm_idx];
+  // (the record may live in HBM -- fused kernel -- so it is read once into registers and written back on success)
+  DAsm* const as_mem = &cx.as[asm_idx];
+  DAsm as_val = *as_mem;
+  DAsm* as = &as_val;
   int4 info = cx.asm_info[asm_idx];
   const int* rec = asm_rec(dc, info.z);
   uint32_t max_uses = (uint32_t)rec[AR_MAX_USES];
@@ -610,6 +613,7 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
     as->clipped = 0;
   else
     as->uses_count++;
+  *as_mem = as_val;
   cx.asm_dirty = 1;
   return true;
 }

@@ -29,7 +29,18 @@ d=np.diff(out[:,:7].astype(np.int64),axis=1)
 print("phase medians (stamp units):", np.median(d,axis=0), "mean", d.mean(axis=0))
 print("total per block median", np.median(out[:,6].astype(np.int64)-out[:,0].astype(np.int64)))
 print("kernel span", int(out[:,6].max()-out[:,0].min()))
-m = out[:,8] != 0
-if m.any():
-    u = out[m][:, 8:12].astype(np.int64)
-    print("uses envs", int(m.sum()), "of", E, " phases (stage, serial, flush) median:", np.median(np.diff(u,axis=1),axis=0), "max:", np.diff(u,axis=1).max(axis=0))
+cnt=out[:,8].astype(np.int64); rdm=out[:,9].astype(np.int64); okc=out[:,10].astype(np.int64)
+p2=(out[:,3].astype(np.int64)-out[:,2].astype(np.int64))
+# blocks without a use leave slots 8.. from an earlier step: only trust blocks whose P2 was long
+has = p2 > 2000
+print("blocks with uses:", int(has.sum()), " uses/block mean", cnt[has].mean(), " successes/block mean", okc[has].mean())
+for c in range(1,6):
+    for r in range(0,3):
+        for k in range(0,3):
+            sel = has & (cnt==c) & (rdm==r) & (okc==k)
+            if sel.sum() > 20: print(f"count {c} rounds {r+1} ok {k}: n={int(sel.sum())} P2 median {np.median(p2[sel]):.0f} p90 {np.percentile(p2[sel],90):.0f}")
+
+d2 = np.diff(out[:,11:16].astype(np.int64),axis=1)
+pre = out[:,11].astype(np.int64)-out[:,2].astype(np.int64); post = out[:,3].astype(np.int64)-out[:,15].astype(np.int64)
+for name, sel in (("1 failing use", has & (cnt==1) & (okc==0)), ("1 successful use", has & (cnt==1) & (okc==1))):
+    print(name, "n", int(sel.sum()), "stamp2->11", np.median(pre[sel]), "ctx, uses, barrier, flush:", np.median(d2[sel],axis=0), "15->stamp3", np.median(post[sel]))
