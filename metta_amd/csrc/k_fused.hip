@@ -332,15 +332,20 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
   return used;
 }
 
-// ---- P2: assembler uses in action order, independent ones on separate lanes (wave 0 only; no workgroup barrier) -------
+// ---- P2: assembler uses in action order.  Uses that share neither an agent nor the assembler commute: they run in the
+// same round, on separate lanes, the even slots on the acting wave (`wsel` 0) and the odd ones on the other (`wsel` 1), so
+// that two divergent uses do not serialise inside one wave.  All threads of the workgroup call this. ----------------
 #ifndef MG_FUSED_USES_ATTR
 #define MG_FUSED_USES_ATTR __forceinline__
 #endif
-__device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, Ctx& cx, const int count, const int lane) {
+__device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, Ctx& cx, const int count, const int lane,
+                                                 const int wsel) {
   const uint8_t* recs = l.pend;
   uint8_t* rounds = (uint8_t*)l.order;  // [A] bytes
   // round of use q = 1 + the latest round among earlier uses that share an agent or the assembler with it
-  if (count == 1) {
+  if (wsel != 0) {
+    // (the acting wave orders the uses)
+  } else if (count == 1) {
     if (lane == 0) {
       rounds[0] = 0;
       l.flags[0] = 0;
@@ -366,10 +371,9 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
     l.flags[0] = max_round;
     l.flags[2] = 0;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
   const int max_round = l.flags[0];
-  if (a.dbg && lane == 0) {
+  if (a.dbg && lane == 0 && wsel == 0) {
     a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 8] = (unsigned long long)count;
     a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 9] = (unsigned long long)max_round;
     a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 10] = 0;
@@ -377,7 +381,7 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
   for (int rd = 0; rd <= max_round; rd++) {
     for (int q0 = 0; q0 < count; q0 += MG_FUSED_SLOTS) {
       const int q = q0 + lane;
-      if (lane < MG_FUSED_SLOTS && q < count && rounds[q] == rd) {
+      if (lane < MG_FUSED_SLOTS && (lane & 1) == wsel && q < count && rounds[q] == rd) {
         const uint8_t* rec = recs + q * 32;
         const int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
         const int act = *(const int*)(rec + 4);
@@ -399,8 +403,7 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
         }
         if (cx.asm_dirty) l.flags[2] = 1;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
   }
 }
@@ -595,19 +598,12 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArg
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(2);
     const int n_uses = l.flags[3];
-#define MG_STAMPL(slot) do { if (a.dbg && wave == actor && lane == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + (slot)] = clock64(); } while (0)
     if (n_uses > 0) {  // block-uniform
       Ctx cx;
-      MG_STAMPL(11);
       mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
       cx.grid = nullptr;
-      MG_STAMPL(12);
-      if (wave == actor) mg_fused_uses(a, l, cx, n_uses, lane);
-      MG_STAMPL(13);
-      __syncthreads();
-      MG_STAMPL(14);
+      mg_fused_uses(a, l, cx, n_uses, lane, wave == actor ? 0 : 1);  // (ends with a workgroup barrier)
       mg_flush_stats(a, l, cx, e, tid, nt);
-      MG_STAMPL(15);
     }
     MG_STAMP(3);
   }

@@ -40,7 +40,14 @@ for c in range(1,6):
             sel = has & (cnt==c) & (rdm==r) & (okc==k)
             if sel.sum() > 20: print(f"count {c} rounds {r+1} ok {k}: n={int(sel.sum())} P2 median {np.median(p2[sel]):.0f} p90 {np.percentile(p2[sel],90):.0f}")
 
-d2 = np.diff(out[:,11:16].astype(np.int64),axis=1)
-pre = out[:,11].astype(np.int64)-out[:,2].astype(np.int64); post = out[:,3].astype(np.int64)-out[:,15].astype(np.int64)
-for name, sel in (("1 failing use", has & (cnt==1) & (okc==0)), ("1 successful use", has & (cnt==1) & (okc==1))):
-    print(name, "n", int(sel.sum()), "stamp2->11", np.median(pre[sel]), "ctx, uses, barrier, flush:", np.median(d2[sel],axis=0), "15->stamp3", np.median(post[sel]))
+tot = out[:,6].astype(np.int64)-out[:,0].astype(np.int64)
+idx = np.argsort(-tot)[:12]
+print("slowest blocks: total, phases P0 P1 P2 tok enc tail, uses count / ok")
+for i in idx:
+    print(int(tot[i]), d[i].tolist(), int(cnt[i]) if has[i] else 0, int(okc[i]) if has[i] else 0)
+p1 = d[:,1]
+print("P1 median: no queued use", np.median(p1[~has]), " p10", np.percentile(p1[~has],10), "| count1", np.median(p1[has&(cnt==1)]), "| count2", np.median(p1[has&(cnt==2)]), "| count3", np.median(p1[has&(cnt==3)]))
+print("P0 percentiles [10,50,90,99]:", np.percentile(d[:,0],[10,50,90,99]), " enc:", np.percentile(d[:,4],[10,50,90,99]), " tok:", np.percentile(d[:,3],[10,50,90,99]))
+print("P1 percentiles [50,90,99,100]: no queued use", np.percentile(p1[~has],[50,90,99,100]), " with", np.percentile(p1[has],[50,90,99,100]))
+big = p1 > 30000
+print("blocks with P1 > 30k:", int(big.sum()), " of which with queued uses", int((big&has).sum()), " P0 median of those", np.median(d[big,0]) if big.any() else 0, " count hist", np.bincount(cnt[big&has].astype(int))[:8] if (big&has).any() else 0)
