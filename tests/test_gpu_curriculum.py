@@ -234,3 +234,49 @@ def test_curriculum_vecenv_completes_tasks_with_their_episode_rewards():
     ep = [i for i in infos if "attributes" in i]
     assert {i["attributes"]["max_steps"] for i in ep} == {40, 25, 33}
     env.close()
+
+
+def test_curriculum_vecenv_on_a_device_generated_pool():
+    """Tasks and maps both live in the pool: 2E device-drawn map slots, each with its own configuration slot; a refresh
+    redraws idle maps and rebuilds their templates with the configuration the slot plays now."""
+    import torch
+
+    from metta_amd.vecenv import CurriculumDeviceVecEnv
+    from oracle.mg_oracle import make_oracle_env
+
+    tasks = _tasks()
+    cur = _Curriculum(tasks)
+    E, A = 3, 24
+    env = CurriculumDeviceVecEnv(cur, E, device=0, seed=40, device_maps=True, map_seed=3, map_refresh_every=7)
+    env.stats_every = 1
+    env.async_reset()
+    slot_task = [(1 + s) % 3 for s in range(2 * E)]
+    comps = [compile_game(t, init_obs_passes=2) for t in tasks]
+    slot_of = list(range(E))
+    b = env.batch
+    oras = [make_oracle_env(comps[slot_task[s]], b.get_map(s), 40 + e) for e, s in enumerate(slot_of)]
+    next_draw = 1 + 2 * E
+    g = torch.Generator().manual_seed(9)
+    maps_seen = [set() for _ in range(E)]
+    for t in range(1, 150):
+        o, r, d, tr, ta, info, ids, mask = env.recv()
+        obs = o.cpu().numpy().reshape(E, A, -1, 3)
+        rew = r.cpu().numpy().reshape(E, A)
+        for e in range(E):
+            assert np.array_equal(obs[e], oras[e].obs), f"step {t} env {e}"
+            assert np.array_equal(rew[e], oras[e].rewards if t > 1 else np.zeros(A, np.float32)), f"step {t} env {e}: rewards"
+        acts = torch.randint(0, 5, (E, A), generator=g, dtype=torch.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                s = slot_of[e]
+                slot_task[s] = next_draw % 3
+                next_draw += 1
+                s = slot_of[e] = (s + E) % (2 * E)
+                m = b.get_map(s)
+                maps_seen[e].add(m.tobytes())
+                oras[e] = make_oracle_env(comps[slot_task[s]], m, 40 + e)
+            oras[e].step(acts[e].numpy())
+        env.send(acts.reshape(-1).cuda())
+    assert len(cur.updates) >= 9 and all(len(s) >= 3 for s in maps_seen)
+    b.check_errors()
+    env.close()
