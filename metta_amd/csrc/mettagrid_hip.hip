@@ -3,13 +3,19 @@
 // Replaces, for the environment-step path, the reference's pybind11 core `MettaGrid`
 // (packages/mettagrid/cpp/bindings/mettagrid_c.cpp).  Layout and kernel design: DESIGN.md.
 //
-// This file is the host side (handle, map pool upload, launches, inspection).  The kernels live in their own
-// translation units (shared device code: mg_kernels.h, mg_sim.h):
-//   k_act_fast.hip  mg_act_fast_kernel   wave-parallel actions, one wave per environment (attack-free configs, A <= 64)
-//   k_uses.hip      mg_uses_kernel       the assembler uses handed over by the fast kernel
-//   k_act.hip       mg_act_kernel        general action kernel (attack / transfer / chests / damage / regen, any A)
-//   k_obs.hip       mg_obs_kernel        token lists, observation rows (aligned 16-byte non-temporal stores), rewards, flags
-//   k_reset.hip     mg_reset_kernel      MettaGrid construction + step-0 observations
+// This file is the host side (handle, map pool upload, launches, pool services, inspection).  The kernels live in their
+// own translation units (shared device code: mg_kernels.h, mg_sim.h):
+//   k_fused.hip        mg_step_fused_kernel  the whole step of one environment in one 2-wave workgroup (attack-free
+//   k_fused_nomod.hip                        configs, A <= 64: arena, navigation); the second file is the same source
+//                                            built without inventory-limit modifiers
+//   k_act_fast.hip     mg_act_fast_kernel    three-launch variant of the same class (MG_NO_FUSED=1): wave-parallel actions,
+//   k_uses.hip         mg_uses_kernel        the assembler uses handed over by it,
+//   k_obs.hip          mg_obs_kernel         token lists, observation rows, rewards, flags (also the general path's second launch)
+//   k_act.hip          mg_act_kernel         general action kernel: rank-ordered parallel rounds (attack / transfer / chests /
+//                                            damage / regen, any A); BIG = grids and records in HBM
+//   k_reset.hip        mg_reset_kernel       MettaGrid construction + step-0 observations; builds the episode-start templates
+//   k_mapgen.hip       mg_generate_maps_kernel  device map pool (border + uniform shuffle per room) and its refresh
+//   advantage.hip      mg_advantage_kernel   V-trace / GAE row scan (mg_compute_advantage)
 //
 // There is no CPU fallback: every entry point runs HIP kernels or fails.
 #include <hip/hip_runtime.h>
