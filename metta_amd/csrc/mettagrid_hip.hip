@@ -170,6 +170,7 @@ struct mg_handle {
   int* d_map_cfg = nullptr;           // [P] (lives with the pool)
   int* d_tlist = nullptr;             // [P] staging for template rebuild lists (lives with the pool)
   int ts[4] = {0, 0, 0, 0};           // token-list strides TSW, TSA, TSS, TSC the pool was sized for
+  int ts_need[4] = {0, 0, 0, 0};      // the largest strides among the tasks written before the pool existed
 };
 
 // ---- static scratch of the allocation-free step (mg_step_noalloc) ---------------------------------------------
@@ -487,6 +488,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   if (h->n_cfg_slots > 0) {  // room for tasks that show a few more tokens per object than the base configuration
     ts_[1] += 4; ts_[2] += 4; ts_[3] += 4;
   }
+  for (int i = 0; i < 4; i++) ts_[i] = std::max(ts_[i], h->ts_need[i]);
   int TSW = ts_[0], TSA = ts_[1], TSS = ts_[2], TSC = ts_[3];
   if (TSW > 255 || TSA > 255 || TSS > 255 || TSC > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
   TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3; TSC = (TSC + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time
@@ -924,6 +926,8 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
   mg_token_strides(v, ts);
   if (h->maps_set && (ts[0] > h->ts[0] || ts[1] > h->ts[1] || ts[2] > h->ts[2] || ts[3] > h->ts[3]))
     return differs("tokens per object (more than the pool was sized for)");
+  if (!h->maps_set)  // the pool is sized later: for the widest task seen until then
+    for (int i = 0; i < 4; i++) h->ts_need[i] = std::max(h->ts_need[i], ts[i]);
   std::vector<int32_t> dcfg = mg_build_dcfg(v);
   while (dcfg.size() % 4) dcfg.push_back(0);
   KArgs& k = h->k;
