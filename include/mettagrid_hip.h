@@ -211,6 +211,14 @@ int mg_env_table(mg_handle* h, uint32_t* out, void* stream);
  * (reference: `get_episode_rewards`, mettagrid_c.cpp:928-930, read by StatsTracker.on_episode_end). */
 int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, void* stream);
 
+/* The same for n environments at once (what `StatsTracker.on_episode_end`, envs/stats_tracker.py:26-107, reads per episode:
+ * `get_episode_stats()` + `get_episode_rewards()` of the episode that has just ended): agent_values / agent_touched
+ * [n][A][SA], game_values / game_touched [n][SG], rewards [n][A], steps [n], host arrays.  One gather launch and one
+ * device -> host copy per 256 environments, so a vecenv that reports several finished episodes per step stays off the
+ * critical path. */
+int mg_finished_batch(mg_handle* h, int n, const int32_t* env_ids, float* agent_values, uint8_t* agent_touched,
+                      float* game_values, uint8_t* game_touched, float* rewards, uint32_t* steps, void* stream);
+
 /* `MettaGrid::set_inventory` (mettagrid_c.cpp:959-965; Agent::set_inventory, agent.cpp:54-72): items/amounts in
  * the iteration order of the converted map (the host language orders them, metta_amd/umap.py). */
 int mg_set_inventory(mg_handle* h, int env, int agent, int n, const int32_t* items, const int32_t* amounts, void* stream);

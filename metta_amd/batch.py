@@ -329,6 +329,30 @@ class MettaGridBatch:
         self._check(self.L.mg_finished_rewards(self._h, env, _p(r, ct.c_float), ct.byref(steps), self._stream()))
         return r, int(steps.value)
 
+    def finished_batch(self, env_ids: Sequence[int]):
+        """The last finished episode of several environments in one device round trip: (agent_values [n, A, SA],
+        agent_touched [n, A, SA] bool, game_values [n, SG], game_touched [n, SG] bool, episode_rewards [n, A], steps [n])."""
+        ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+        n, A = len(ids), self.num_agents
+        Sa, Sg = len(self.compiled.agent_slot_names[0]), len(self.compiled.game_slot_names)
+        av, at = np.zeros((n, A, Sa), np.float32), np.zeros((n, A, Sa), np.uint8)
+        gv, gt = np.zeros((n, Sg), np.float32), np.zeros((n, Sg), np.uint8)
+        rew, steps = np.zeros((n, A), np.float32), np.zeros(n, np.uint32)
+        if n:
+            self._check(
+                self.L.mg_finished_batch(
+                    self._h, n, _p(ids, ct.c_int32), _p(av, ct.c_float), _p(at, ct.c_uint8), _p(gv, ct.c_float),
+                    _p(gt, ct.c_uint8), _p(rew, ct.c_float), _p(steps, ct.c_uint32), self._stream(),
+                )
+            )  # fmt: skip
+        return av, at.astype(bool), gv, gt.astype(bool), rew, steps
+
+    def map_agent_groups(self, map_id: int) -> list[int]:
+        """Group index of every agent of map slot `map_id`, in agent-id order (the row-major order of the agent cells)."""
+        flat = self.map_pool[map_id].reshape(-1)
+        c = self.compiled
+        return [c.cell_group[int(v) - 1] for v in flat if v != 0 and c.cell_kinds[int(v) - 1] == 2]
+
     def current_step(self, env: int) -> int:
         return self.env_info(env)["current_step"]
 

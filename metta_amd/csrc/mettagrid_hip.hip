@@ -93,6 +93,29 @@ __global__ void mg_set_inventory_kernel(KArgs a, int e, int agent, int n, const 
   a.agents[(size_t)e * a.A + agent] = *ag;
 }
 
+// Gather the finished-episode snapshots of the listed environments into one contiguous block (mg_finished_batch):
+// per env [A*SA astats | A*TW atouched | SG gstats | GW gtouched | A episode rewards | steps].
+__global__ void mg_gather_finished_kernel(KArgs a, const int* envs, uint32_t* out, int row_words) {
+  const int e = envs[blockIdx.x];
+  uint32_t* dst = out + (size_t)blockIdx.x * row_words;
+  const int n0 = a.A * a.SA, n1 = a.A * a.TW, n2 = a.SG, n3 = a.GW, n4 = a.A;
+  const uint32_t* s0 = (const uint32_t*)(a.fin_astats + (size_t)e * n0);
+  const uint32_t* s1 = a.fin_atouched + (size_t)e * n1;
+  const uint32_t* s2 = (const uint32_t*)(a.fin_gstats + (size_t)e * n2);
+  const uint32_t* s3 = a.fin_gtouched + (size_t)e * n3;
+  const uint32_t* s4 = (const uint32_t*)(a.fin_ep_rewards + (size_t)e * n4);
+  for (int i = threadIdx.x; i < n0; i += blockDim.x) dst[i] = s0[i];
+  dst += n0;
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) dst[i] = s1[i];
+  dst += n1;
+  for (int i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = s2[i];
+  dst += n2;
+  for (int i = threadIdx.x; i < n3; i += blockDim.x) dst[i] = s3[i];
+  dst += n3;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = s4[i];
+  if (threadIdx.x == 0) dst[n4] = a.fin_steps[e];
+}
+
 __global__ void mg_fill_u8(uint8_t* p, size_t n, uint8_t v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -171,6 +194,15 @@ struct mg_handle {
   int* d_tlist = nullptr;             // [P] staging for template rebuild lists (lives with the pool)
   int ts[4] = {0, 0, 0, 0};           // token-list strides TSW, TSA, TSS, TSC the pool was sized for
   int ts_need[4] = {0, 0, 0, 0};      // the largest strides among the tasks written before the pool existed
+  // pinned staging ring for the small host -> device uploads of the pool services (task streams, template lists):
+  // an upload never waits for the stream, only for the ring slot's own previous upload
+  int32_t* ring = nullptr;
+  size_t ring_words = 0;
+  int ring_next = 0;
+  std::vector<hipEvent_t> ring_ev;
+  std::vector<char> ring_used;
+  uint32_t* d_fin_stage = nullptr;  // [MG_FIN_CHUNK][row] device staging of mg_finished_batch
+  int* d_fin_envs = nullptr;        // [MG_FIN_CHUNK]
 };
 
 // ---- static scratch of the allocation-free step (mg_step_noalloc) ---------------------------------------------
@@ -874,10 +906,36 @@ int mg_set_config_slots(mg_handle* h, int num_slots, int headroom_words) {
   return 0;
 }
 
+#define MG_RING_SLOTS 32
+// Upload `words` int32 from `src` to `dst` on `st` through the pinned ring (falls back to a synchronous copy when the
+// block is larger than a ring slot).
+static int mg_upload(mg_handle* h, int32_t* dst, const int32_t* src, size_t words, hipStream_t st) {
+  if (!h->ring) {
+    h->ring_words = std::max<size_t>(256, (size_t)h->k.dc_stride);
+    HIPCHK(hipHostMalloc((void**)&h->ring, h->ring_words * 4 * MG_RING_SLOTS, hipHostMallocDefault));
+    h->ring_ev.resize(MG_RING_SLOTS);
+    h->ring_used.assign(MG_RING_SLOTS, 0);
+    for (auto& e : h->ring_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  if (words > h->ring_words) {
+    HIPCHK(hipMemcpyAsync(dst, src, words * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+  }
+  const int i = h->ring_next;
+  h->ring_next = (i + 1) % MG_RING_SLOTS;
+  if (h->ring_used[(size_t)i]) HIPCHK(hipEventSynchronize(h->ring_ev[(size_t)i]));
+  int32_t* stage = h->ring + (size_t)i * h->ring_words;
+  memcpy(stage, src, words * 4);
+  HIPCHK(hipMemcpyAsync(dst, stage, words * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(h->ring_ev[(size_t)i], st));
+  h->ring_used[(size_t)i] = 1;
+  return 0;
+}
+
 static int mg_rebuild_templates(mg_handle* h, const std::vector<int>& maps, hipStream_t st) {
   if (maps.empty()) return 0;
-  HIPCHK(hipMemcpyAsync(h->d_tlist, maps.data(), maps.size() * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // (the list is a stack vector of the caller)
+  if (mg_upload(h, h->d_tlist, maps.data(), maps.size(), st)) return 1;
   KArgs kt = h->kt;
   kt.map_max_steps = h->k.map_max_steps;
   kt.map_cfg = h->k.map_cfg;
@@ -938,8 +996,7 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
   if (mg_use_device(h)) return 1;
   hipStream_t st = (hipStream_t)stream;
   dcfg.resize((size_t)k.dc_stride, 0);
-  HIPCHK(hipMemcpyAsync(const_cast<int*>(k.gdc) + (size_t)slot * k.dc_stride, dcfg.data(), dcfg.size() * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));  // (dcfg is a local)
+  if (mg_upload(h, const_cast<int*>(k.gdc) + (size_t)slot * k.dc_stride, dcfg.data(), dcfg.size(), st)) return 1;
   // a task outside the wave-parallel / modifier-free fast paths moves the whole handle to the general kernels
   if (k.fast && !mg_fast_eligible(v)) {
     k.fast = 0;
@@ -971,7 +1028,7 @@ int mg_assign_map_configs(mg_handle* h, int n, const int32_t* map_ids, const int
     maps.push_back(map_ids[i]);
   }
   // (P ints: re-upload the table; stream-ordered after the steps already queued)
-  HIPCHK(hipMemcpyAsync(h->d_map_cfg, h->host_map_cfg.data(), h->host_map_cfg.size() * 4, hipMemcpyHostToDevice, st));
+  if (mg_upload(h, h->d_map_cfg, h->host_map_cfg.data(), h->host_map_cfg.size(), st)) return 1;
   return mg_rebuild_templates(h, maps, st);
 }
 
@@ -1450,6 +1507,56 @@ int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, 
   return 0;
 }
 
+// The last finished episode of several environments at once: one gather launch and one device -> host copy per chunk of
+// environments instead of six blocking copies per environment (mg_episode_stats(last_finished) + mg_finished_rewards).
+#define MG_FIN_CHUNK 256
+int mg_finished_batch(mg_handle* h, int n, const int32_t* env_ids, float* agent_values, uint8_t* agent_touched, float* game_values,
+                      uint8_t* game_touched, float* rewards, uint32_t* steps, void* stream) {
+  if (!h || (n > 0 && (!env_ids || !agent_values || !agent_touched || !game_values || !game_touched || !rewards || !steps)))
+    return fail("mg_finished_batch: NULL argument");
+  for (int i = 0; i < n; i++)
+    if (env_ids[i] < 0 || env_ids[i] >= h->E) return fail("mg_finished_batch: environment id out of range");
+  if (n <= 0) return 0;
+  if (mg_use_device(h)) return 1;
+  const KArgs& k = h->k;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n0 = (size_t)k.A * k.SA, n1 = (size_t)k.A * k.TW, n2 = (size_t)k.SG, n3 = (size_t)k.GW, n4 = (size_t)k.A;
+  const size_t row = n0 + n1 + n2 + n3 + n4 + 1;
+  if (!h->d_fin_stage) {
+    if (dalloc(h, &h->d_fin_stage, row * MG_FIN_CHUNK)) return 1;
+    if (dalloc(h, &h->d_fin_envs, (size_t)MG_FIN_CHUNK)) return 1;
+  }
+  std::vector<uint32_t> host(row * (size_t)std::min(n, MG_FIN_CHUNK));
+  for (int c0 = 0; c0 < n; c0 += MG_FIN_CHUNK) {
+    const int m = std::min(MG_FIN_CHUNK, n - c0);
+    HIPCHK(hipMemcpyAsync(h->d_fin_envs, env_ids + c0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mg_gather_finished_kernel, dim3((unsigned)m), dim3(256), 0, st, k, h->d_fin_envs, h->d_fin_stage, (int)row);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host.data(), h->d_fin_stage, row * (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < m; i++) {
+      const uint32_t* src = host.data() + row * (size_t)i;
+      const size_t o = (size_t)(c0 + i);
+      float* av = agent_values + o * n0;
+      uint8_t* at = agent_touched + o * n0;
+      memcpy(av, src, n0 * 4);
+      const uint32_t* tb = src + n0;
+      // a key exists once touched: explicit bit (set-type slots) or a non-zero value (counters only grow from 0)
+      for (int a = 0; a < k.A; a++)
+        for (int s = 0; s < k.SA; s++) {
+          const uint32_t bit = (tb[(size_t)a * k.TW + (s >> 5)] >> (s & 31)) & 1u;
+          at[(size_t)a * k.SA + s] = (bit || av[(size_t)a * k.SA + s] != 0.f) ? 1 : 0;
+        }
+      memcpy(game_values + o * n2, src + n0 + n1, n2 * 4);
+      const uint32_t* gb = src + n0 + n1 + n2;
+      for (int s = 0; s < k.SG; s++) game_touched[o * n2 + (size_t)s] = (gb[(size_t)(s >> 5)] >> (s & 31)) & 1u;
+      memcpy(rewards + o * n4, src + n0 + n1 + n2 + n3, n4 * 4);
+      steps[o] = src[n0 + n1 + n2 + n3 + n4];
+    }
+  }
+  return 0;
+}
+
 // Diagnostic: per-environment cycle stamps of the observation kernel's phases (s_memtime, 100 MHz units on gfx950).
 int mg_debug_stamps(mg_handle* h, unsigned long long* out, int enable) {
   if (!h) return fail("mg_debug_stamps: NULL handle");
@@ -1469,6 +1576,8 @@ int mg_destroy(mg_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   for (void* p : h->map_allocs) (void)hipFree(p);
   for (auto& e : h->ev) (void)hipEventDestroy(e);
+  for (auto& e : h->ring_ev) (void)hipEventDestroy(e);
+  if (h->ring) (void)hipHostFree(h->ring);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   for (int i = 0; i < 7; i++) {
     if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);

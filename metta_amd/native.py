@@ -82,6 +82,7 @@ SYMBOLS = {
     "mg_env_info": (ct.c_int, [_vp, ct.c_int, _u32p, _i32p, _u32p, _u32p, _vp]),
     "mg_env_table": (ct.c_int, [_vp, _u32p, _vp]),
     "mg_finished_rewards": (ct.c_int, [_vp, ct.c_int, _f32p, _u32p, _vp]),
+    "mg_finished_batch": (ct.c_int, [_vp, ct.c_int, _i32p, _f32p, _u8p, _f32p, _u8p, _f32p, _u32p, _vp]),
     "mg_set_inventory": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _vp]),
     "mg_summary_buffer": (ct.c_int, [_vp, ct.POINTER(ct.POINTER(ct.c_double)), _i32p]),
     "mg_finished_summary": (ct.c_int, [_vp, _f64p, ct.c_int, _vp]),

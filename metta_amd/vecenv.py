@@ -349,37 +349,69 @@ class MettaGridDeviceVecEnv:
 
     def _collect_finished(self) -> None:
         """Low-sync variant: episodes whose counter advanced since the last poll, from the snapshot the act kernel
-        takes when it restarts an environment (only the latest finished episode of an env is kept)."""
+        takes when it restarts an environment (only the latest finished episode of an env is kept).  All of them are
+        fetched in one device round trip (`mg_finished_batch`) and decoded with numpy: with thousands of environments
+        several episodes end per step, and six blocking copies plus a Python loop over 24 x 100 slots for each of them
+        would cost more than the step itself."""
         b = self.batch
         table = b.env_table()
         if table[:, 7].any():
             b.check_errors()  # raises, naming the first environment and the decoded bits
+        envs = np.nonzero(table[:, 4] > self._episodes_seen)[0]
+        if len(envs) == 0:
+            return
         A = self.agents_per_env
-        for e in np.nonzero(table[:, 4] > self._episodes_seen)[0].tolist():
+        c = self.compiled
+        av, at, gv, gt, rew, steps = b.finished_batch(envs)
+        one_group = len(c.agent_slot_names) == 1
+        now = time.time()
+        for i, e in enumerate(envs.tolist()):
             self._episodes_seen[e] = int(table[e, 4])
-            stats = b.get_episode_stats(e, last_finished=True)
-            ep_rewards, steps = b.finished_rewards(e)
             # the table already names the map of the episode that has just begun
             prev_map = (int(table[e, 3]) - getattr(b, "map_stride", 1)) % len(b.map_pool)
+            vals = av[i].astype(np.float64) * at[i]
             agent: dict[str, float] = {}
-            for st in stats["agent"]:
-                for k, v in st.items():
-                    agent[k] = agent.get(k, 0) + v
-            self._per_label_rewards[self._label] = float(ep_rewards.mean())
+            if one_group:
+                names = c.agent_slot_names[0]
+                sums = vals.sum(axis=0)
+                for s in np.nonzero(at[i].any(axis=0))[0].tolist():
+                    agent[names[s]] = float(sums[s]) / A
+            else:  # slot names carry the group's name: sum per group, merge by key
+                groups = np.asarray(self._map_groups(prev_map))
+                for g in np.unique(groups).tolist():
+                    sel = groups == g
+                    names = c.agent_slot_names[g]
+                    sums = vals[sel].sum(axis=0)
+                    for s in np.nonzero(at[i][sel].any(axis=0))[0].tolist():
+                        agent[names[s]] = agent.get(names[s], 0.0) + float(sums[s])
+                agent = {k: v / A for k, v in agent.items()}
+            game = {c.game_slot_names[s]: float(gv[i, s]) for s in np.nonzero(gt[i])[0].tolist()}
+            mean_reward = float(rew[i].mean())
+            self._per_label_rewards[self._label] = mean_reward
             self.infos.append(
                 {
-                    "game": stats["game"],
-                    "agent": {k: v / A for k, v in agent.items()},
+                    "game": game,
+                    "agent": agent,
                     "per_label_rewards": dict(self._per_label_rewards),
-                    "per_label_chest_deposits": self._chest_deposits(stats["game"]),
+                    "per_label_chest_deposits": self._chest_deposits(game),
                     "attributes": {
                         "seed": int(table[e, 2]), "map_w": int(b.map_dims[prev_map, 1]),
-                        "map_h": int(b.map_dims[prev_map, 0]), "steps": steps,
-                        "max_steps": self._slot_max_steps(prev_map), "completion_time": time.time(),
+                        "map_h": int(b.map_dims[prev_map, 0]), "steps": int(steps[i]),
+                        "max_steps": self._slot_max_steps(prev_map), "completion_time": now,
                     },
                 }
-            )
-            self._episode_finished(e, prev_map, float(ep_rewards.mean()), self.infos[-1], current_slot=int(table[e, 3]))
+            )  # fmt: skip
+            self._episode_finished(e, prev_map, mean_reward, self.infos[-1], current_slot=int(table[e, 3]))
+
+    def _map_groups(self, map_slot: int) -> list:
+        """Agent groups of a map slot; cached for uploaded pools (a device-generated slot is read back each time)."""
+        b = self.batch
+        if getattr(b, "generated", False):
+            return b.map_agent_groups(map_slot)
+        cache = self.__dict__.setdefault("_groups_cache", {})
+        if map_slot not in cache:
+            cache[map_slot] = b.map_agent_groups(map_slot)
+        return cache[map_slot]
 
 
 class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):

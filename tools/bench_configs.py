@@ -4,6 +4,7 @@
   python3 tools/bench_configs.py navigation   # 8192 envs x 4 agents, 64 maps of mixed sizes (60..120)^2
   python3 tools/bench_configs.py combat [steps] [envs]  # 64 (default) envs x 1024 agents on 256 x 256 maps (grid tiles in HBM)
   python3 tools/bench_configs.py mapgen       # 4096 arena envs, 8192 device-generated slots: cost of one pool refresh
+  python3 tools/bench_configs.py curriculum   # 4096 arena envs under CurriculumDeviceVecEnv: three tasks, 500-step episodes
   python3 tools/bench_configs.py rollout      # configs[4] on one GPU: 4096 arena envs x 24 agents + LSTM policy (bf16)
 """
 import json
@@ -28,6 +29,8 @@ def main():
         return rollout_bench(steps)
     if which == "mapgen":
         return mapgen_bench()
+    if which == "curriculum":
+        return curriculum_bench()
     if which == "navigation":
         A, E = 4, 8192
         cfg = make_navigation(A)
@@ -107,6 +110,71 @@ def mapgen_bench():
     b.check_errors()
     print(json.dumps(out))
     b.close()
+
+
+def curriculum_bench():
+    import copy
+
+    from metta_amd.builder import make_arena
+    from metta_amd.vecenv import CurriculumDeviceVecEnv
+
+    class Task:
+        def __init__(self, i, cfg):
+            self._task_id, self.cfg, self.n = i, cfg, 0
+
+        def get_env_cfg(self):
+            return self.cfg
+
+        def complete(self, score):
+            self.n += 1
+
+    class Cur:
+        def __init__(self):
+            base = make_arena(24)
+            base.game.max_steps = 500
+            self.tasks = []
+            for i, (w, ms) in enumerate(((1.0, 500), (0.5, 400), (0.1, 450))):
+                c = copy.deepcopy(base)
+                c.game.max_steps = ms
+                c.game.agent.rewards.inventory = {"heart": w, "ore_red": 0.1 * i}
+                self.tasks.append(Task(i, c))
+            self.k = 0
+
+        def get_task(self):
+            self.k += 1
+            return self.tasks[self.k % 3]
+
+        def update_task_performance(self, task_id, score):
+            pass
+
+        def stats(self):
+            return {"n": float(self.k)}
+
+    E = 4096
+    cur = Cur()
+    t0 = time.perf_counter()
+    env = CurriculumDeviceVecEnv(cur, E, device=0, seed=0, device_maps=True, early_reset=True)
+    env.async_reset()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    table = torch.randint(0, 5, (16, E * 24), device="cuda", dtype=torch.int32)
+    for t in range(50):
+        env.recv()
+        env.send(table[t % 16])
+    torch.cuda.synchronize()
+    done0 = env.tasks_completed
+    t0 = time.perf_counter()
+    steps = 1000
+    for t in range(steps):
+        env.recv()
+        env.send(table[t % 16])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"workload": "curriculum: 4096 arena envs, 3 tasks, 400-500 step episodes, device maps, async infos",
+                      "setup_s": t_setup, "ms_per_step": dt / steps * 1e3, "agent_steps_per_s": E * 24 * steps / dt,
+                      "tasks_completed": env.tasks_completed - done0, "host_syncs": env.host_syncs}))
+    env.batch.check_errors()
+    env.close()
 
 
 def rollout_bench(steps):
