@@ -1,4 +1,4 @@
-// k_act.hip -- general action kernel (attack / transfer / swaps / chests / regeneration / damage, any number of agents).
+// k_act_body.h -- general action kernel (attack / transfer / swaps / chests / regeneration / damage, any number of agents).
 //
 // Reference: the shuffled sequential loop of MettaGrid::_step (bindings/mettagrid_c.cpp:588-650): agents act one
 // after the other in std::shuffle order and interact through the grid, through each other's inventories (attack,
@@ -384,24 +384,48 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   }
 }
 
-int mg_act_threads(const KArgs& k) {
+// ---- one kernel instantiation per translation unit (k_act_dcl.hip / k_act_nodcl.hip / k_act_big.hip define
+// MG_ACT_VARIANT and include this file): the three of them compile side by side instead of one after the other ----
+static inline int mg_act_threads_i(const KArgs& k) {
   int t = (k.A + 63) & ~63;
   return t < 256 ? 256 : (t > MG_ACT_MAX_THREADS ? MG_ACT_MAX_THREADS : t);
 }
+#if MG_ACT_VARIANT == 0
+#define MG_ACT_KERNEL mg_act_kernel<true, false>
+#define MG_ACT_NAME(x) x##_dcl
+#elif MG_ACT_VARIANT == 1
+#define MG_ACT_KERNEL mg_act_kernel<false, false>
+#define MG_ACT_NAME(x) x##_nodcl
+#else
+#define MG_ACT_KERNEL mg_act_kernel<false, true>
+#define MG_ACT_NAME(x) x##_big
+#endif
+void MG_ACT_NAME(mg_launch_act)(const KArgs& k, unsigned n, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((MG_ACT_KERNEL), dim3(n), dim3((unsigned)mg_act_threads_i(k)), lds, st, k);
+}
+hipError_t MG_ACT_NAME(mg_raise_lds_cap_act)(int cap) {
+  return hipFuncSetAttribute((const void*)MG_ACT_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+}
+#if MG_ACT_VARIANT == 0
+void mg_launch_act_nodcl(const KArgs& k, unsigned n, size_t lds, hipStream_t st);
+void mg_launch_act_big(const KArgs& k, unsigned n, size_t lds, hipStream_t st);
+hipError_t mg_raise_lds_cap_act_nodcl(int cap);
+hipError_t mg_raise_lds_cap_act_big(int cap);
+int mg_act_threads(const KArgs& k) { return mg_act_threads_i(k); }
 size_t mg_act_lds_bytes(const KArgs& k, bool dcl, bool big) {
   return mg_carve_act<false>(nullptr, nullptr, nullptr, big ? 0 : k.HW, big ? 0 : k.A, k.A, k.NAmax, k.NCmax, k.SG, k.NWIN,
                              dcl ? k.dc_words : 0);
 }
 void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st) {
-  const dim3 block((unsigned)mg_act_threads(k));
-  if (big) hipLaunchKernelGGL((mg_act_kernel<false, true>), dim3(n), block, lds, st, k);
-  else if (dcl) hipLaunchKernelGGL((mg_act_kernel<true, false>), dim3(n), block, lds, st, k);
-  else hipLaunchKernelGGL((mg_act_kernel<false, false>), dim3(n), block, lds, st, k);
+  if (big) mg_launch_act_big(k, n, lds, st);
+  else if (dcl) mg_launch_act_dcl(k, n, lds, st);
+  else mg_launch_act_nodcl(k, n, lds, st);
 }
 hipError_t mg_raise_lds_cap_act(int cap) {
-  hipError_t e = hipFuncSetAttribute((const void*)mg_act_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  hipError_t e = mg_raise_lds_cap_act_dcl(cap);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)mg_act_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  e = mg_raise_lds_cap_act_nodcl(cap);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)mg_act_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  return mg_raise_lds_cap_act_big(cap);
 }
+#endif

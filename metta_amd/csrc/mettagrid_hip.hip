@@ -11,7 +11,7 @@
 //   k_act_fast.hip     mg_act_fast_kernel    three-launch variant of the same class (MG_NO_FUSED=1): wave-parallel actions,
 //   k_uses.hip         mg_uses_kernel        the assembler uses handed over by it,
 //   k_obs.hip          mg_obs_kernel         token lists, observation rows, rewards, flags (also the general path's second launch)
-//   k_act.hip          mg_act_kernel         general action kernel: rank-ordered parallel rounds (attack / transfer / chests /
+//   k_act_*.hip        mg_act_kernel         general action kernel: rank-ordered parallel rounds (attack / transfer / chests /
 //                                            damage / regen, any A); BIG = grids and records in HBM
 //   k_reset.hip        mg_reset_kernel       MettaGrid construction + step-0 observations; builds the episode-start templates
 //   k_mapgen.hip       mg_generate_maps_kernel  device map pool (border + uniform shuffle per room) and its refresh

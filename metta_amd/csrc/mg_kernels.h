@@ -1037,7 +1037,7 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
 #define MG_USES_THREADS 64
 void mg_launch_act_fast(const KArgs& k, unsigned n, hipStream_t st);                                   // k_act_fast.hip
 void mg_launch_uses(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);                // k_uses.hip
-void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_act.hip
+void mg_launch_act(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_act_body.h (k_act_dcl / _nodcl / _big.hip)
 size_t mg_act_lds_bytes(const KArgs& k, bool dcl, bool big);
 int mg_act_threads(const KArgs& k);
 void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_obs.hip

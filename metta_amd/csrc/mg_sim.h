@@ -87,7 +87,7 @@ struct Ctx {
   int NC;
   int* gsetv;                         // [R] pending StatsTracker::set of chest.<r>.amount (last writer wins) ...
   uint32_t* gsetm;                    // ... and which of them are pending
-  // Parallel action rounds (k_act.hip): "last writer" means last in the reference's action order, not in time.  Each set
+  // Parallel action rounds (k_act_body.h): "last writer" means last in the reference's action order, not in time.  Each set
   // carries a sequence key (the acting agent's rank, then a per-action counter); the largest key wins (atomic max of
   // key << 16 | amount).  Null = the single-writer form above.
   unsigned long long* gset64;
