@@ -364,3 +364,31 @@ def test_episode_infos_equal_the_reference_stats_tracker(case_name, stats_every)
     ra.pop("completion_time"), oa.pop("completion_time")
     assert oa == ra, (oa, ra)
     v.close()
+
+
+def test_finished_batch_equals_the_per_environment_calls():
+    """`mg_finished_batch` (one gather + one copy for all environments of a poll) returns what `mg_episode_stats(last_finished)`
+    and `mg_finished_rewards` return environment by environment."""
+    from metta_amd.batch import MettaGridBatch
+    from metta_amd.builder import make_arena
+    from tests.helpers import load_map_pool
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 30
+    E = 300  # more than one chunk of 256
+    b = MettaGridBatch(cfg, E, load_map_pool()[:8], device=0, seeds=list(range(E)), map_ids=[e % 8 for e in range(E)])
+    b.set_auto_reset(True, 1)
+    rs = np.random.RandomState(0)
+    for t in range(70):
+        b.step(rs.randint(0, 5, size=E * 24).astype(np.int32))
+    ids = np.array([0, 5, 255, 256, 299, 17], np.int32)
+    av, at, gv, gt, rew, steps = b.finished_batch(ids)
+    for i, e in enumerate(ids.tolist()):
+        av1, at1, gv1, gt1 = b.raw_stats(e, last_finished=True)
+        r1, s1 = b.finished_rewards(e)
+        assert np.array_equal(av[i], av1) and np.array_equal(at[i], at1.astype(bool))
+        assert np.array_equal(gv[i], gv1) and np.array_equal(gt[i], gt1.astype(bool))
+        assert np.array_equal(rew[i], r1) and int(steps[i]) == s1 == 30
+    allv = b.finished_batch(np.arange(E))
+    assert allv[0].shape == (E, 24, av.shape[2]) and (allv[5] == 30).all()
+    b.close()
