@@ -198,6 +198,19 @@ class MettaGridBatch:
         self._check(self.L.mg_get_map(self._h, int(map_id), _p(out, ct.c_uint8), self._stream()))
         return out
 
+    def write_map_slot(self, slot: int, grid) -> None:
+        """Replace map slot `slot` by `grid` (cell names or codes, the pool's size): the reference's per-episode
+        `map_builder.build()` (simulator.py:264-267) for maps built on the host.  Write the slot an environment enters
+        next, not one an episode is on."""
+        arr = np.asarray(grid)
+        enc = arr.astype(np.uint8) if arr.dtype.kind in "ui" else self.compiled.encode_map(arr)
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        if enc.shape != (self.map_height, self.map_width):
+            raise RuntimeError(f"the map is {enc.shape}, the pool's slots are {(self.map_height, self.map_width)}")
+        self._check(self.L.mg_write_map_slot(self._h, int(slot), _p(enc, ct.c_uint8), self._stream()))
+        if not getattr(self, "generated", False):
+            self.map_pool[int(slot)] = enc
+
     def write_config_slot(self, slot: int, cfg) -> None:
         """Compile `cfg` (a MettaGridConfig, or a CompiledGame) into configuration slot `slot`: the device side of
         `CurriculumEnv`'s `env.set_mg_config(task.get_env_cfg())` (curriculum_env.py:111-126).  Raises RuntimeError when

@@ -59,10 +59,12 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
   __shared__ unsigned long long scan[MG_MAPGEN_THREADS];
   __shared__ int kcount[256];
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int m = (int)blockIdx.x;
+  const int m = g.direct_slot >= 0 ? g.direct_slot : (int)blockIdx.x;
   if (tid == 0) {
     int run;
-    if (g.force) {
+    if (g.direct_slot >= 0) {
+      run = 1;
+    } else if (g.force) {
       run = 1;
     } else if (g.inuse[m] == g.gen) {
       g.slot_state[m] = 1;  // an episode is on it: regenerate once it is free again
@@ -77,8 +79,12 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
   if (!go) return;
   const int H = g.height, W = g.width, cells = H * W;
   uint8_t* bytes = smem;
-  for (int i = tid; i < cells; i += nt) bytes[i] = (uint8_t)g.fill_code;
   for (int i = tid; i < 256; i += nt) kcount[i] = 0;
+  if (g.direct_slot >= 0) {  // a map uploaded by the host: only the derived pool entries are built here
+    const uint8_t* src = g.map_bytes + (size_t)m * g.HW8;
+    for (int i = tid; i < cells; i += nt) bytes[i] = src[i];
+  } else {
+  for (int i = tid; i < cells; i += nt) bytes[i] = (uint8_t)g.fill_code;
   __syncthreads();
   for (int rr = 0; rr < g.n_rooms; rr++) {
     const int r0 = g.rooms[4 * rr], c0 = g.rooms[4 * rr + 1], rh = g.rooms[4 * rr + 2], rw = g.rooms[4 * rr + 3];
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
         *y = t;
       }
     }
+  }
   }
   __syncthreads();
   // ---- derive the pool entries of slot m (the host does the same scan in mg_set_maps) -------------------------

@@ -182,6 +182,7 @@ struct mg_handle {
   int* d_iota = nullptr;       // [P] 0 .. P-1
   // device map generator (mg_set_generated_maps / mg_refresh_maps)
   bool generated = false;
+  bool gen_ready = false;      // gen holds the pool's writable pointers and the slot bookkeeping (mg_mapgen_setup)
   MapGenArgs gen;
   uint32_t* d_inuse = nullptr;
   bool in_set_generated = false;
@@ -712,6 +713,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   }
   k.map_max_steps = nullptr;  // (freed with the old pool)
   if (!h->in_set_generated) h->generated = false;
+  h->gen_ready = false;
   h->maps_set = true;
   h->needs_reset = true;
   if (k.map_stride >= num_maps) k.map_stride %= num_maps;
@@ -730,6 +732,39 @@ int mg_set_maps_ragged(mg_handle* h, const uint8_t* maps, int num_maps, const in
 
 // ---- device map generator ---------------------------------------------------------------------------------------
 static int mg_use_device(mg_handle* h);
+// The pool's writable pointers and the slot bookkeeping of the generator kernel (pools whose maps share one size).
+static int mg_mapgen_setup(mg_handle* h, int height, int width) {
+  KArgs& k = h->k;
+  const size_t P = (size_t)k.P;
+  int *d_list, *d_count;
+  uint32_t *d_state, *d_inuse;
+  uint8_t* d_bytes;
+  if (dalloc(h, &d_list, P, true) || dalloc(h, &d_count, 1, true) || dalloc(h, &d_state, P, true) || dalloc(h, &d_inuse, P, true) ||
+      dalloc(h, &d_bytes, P * (size_t)k.HW8, true))
+    return 1;
+  MapGenArgs& g = h->gen;
+  memset(&g, 0, sizeof(g));
+  g.gdc = k.gdc;
+  g.height = height; g.width = width;
+  g.map_cells = const_cast<uint16_t*>(k.map_cells);
+  g.map_cells8 = const_cast<uint8_t*>(k.map_cells8);
+  g.map_bytes = d_bytes;
+  g.map_spawn = const_cast<int4*>(k.map_spawn);
+  g.map_asm = const_cast<int4*>(k.map_asm);
+  g.map_nasm = const_cast<int*>(k.map_nasm);
+  g.map_chest = const_cast<int4*>(k.map_chest);
+  g.map_nchest = const_cast<int*>(k.map_nchest);
+  g.map_objcount = const_cast<float*>(k.map_objcount);
+  g.HW = k.HW; g.HW8 = k.HW8; g.A = k.A; g.NW = k.NW; g.NAmax = k.NAmax; g.NCmax = k.NCmax; g.n_cells = k.n_cells;
+  g.slot_state = d_state; g.inuse = d_inuse; g.gen = 0;
+  g.list = d_list; g.count = d_count; g.status = k.status;
+  g.direct_slot = -1;
+  h->d_inuse = d_inuse;
+  HIPCHK(mg_raise_lds_cap_mapgen(160 * 1024 - 4096));
+  h->gen_ready = true;
+  return 0;
+}
+
 static int mg_refresh_impl(mg_handle* h, int force, hipStream_t st) {
   MapGenArgs g = h->gen;
   g.gen = ++h->gen.gen;
@@ -802,16 +837,12 @@ int mg_set_generated_maps(mg_handle* h, int height, int width, int fill_code, in
   h->in_set_generated = false;
   if (rc) return rc;
   h->maps_set = false;  // (until the first generation below has succeeded)
-  KArgs& k = h->k;
   const int n_sym = room_sym_begin[n_rooms];
-  int *d_rooms, *d_begin, *d_code, *d_cnt, *d_list, *d_count;
-  uint32_t *d_state, *d_inuse;
-  uint8_t* d_bytes;
+  int *d_rooms, *d_begin, *d_code, *d_cnt;
   if (dalloc(h, &d_rooms, (size_t)n_rooms * 4, true) || dalloc(h, &d_begin, (size_t)n_rooms + 1, true) ||
-      dalloc(h, &d_code, (size_t)n_sym, true) || dalloc(h, &d_cnt, (size_t)n_sym, true) || dalloc(h, &d_list, (size_t)num_maps, true) ||
-      dalloc(h, &d_count, 1, true) || dalloc(h, &d_state, (size_t)num_maps, true) || dalloc(h, &d_inuse, (size_t)num_maps, true) ||
-      dalloc(h, &d_bytes, (size_t)num_maps * k.HW8, true))
+      dalloc(h, &d_code, (size_t)n_sym, true) || dalloc(h, &d_cnt, (size_t)n_sym, true))
     return 1;
+  if (mg_mapgen_setup(h, height, width)) return 1;
   HIPCHK(hipMemcpy(d_rooms, rooms, (size_t)n_rooms * 16, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_begin, room_sym_begin, ((size_t)n_rooms + 1) * 4, hipMemcpyHostToDevice));
   if (n_sym > 0) {
@@ -819,25 +850,9 @@ int mg_set_generated_maps(mg_handle* h, int height, int width, int fill_code, in
     HIPCHK(hipMemcpy(d_cnt, sym_count, (size_t)n_sym * 4, hipMemcpyHostToDevice));
   }
   MapGenArgs& g = h->gen;
-  memset(&g, 0, sizeof(g));
-  g.gdc = k.gdc;
-  g.height = height; g.width = width; g.fill_code = fill_code; g.n_rooms = n_rooms;
+  g.fill_code = fill_code; g.n_rooms = n_rooms;
   g.rooms = d_rooms; g.room_sym_begin = d_begin; g.sym_code = d_code; g.sym_count = d_cnt;
-  g.map_cells = const_cast<uint16_t*>(k.map_cells);
-  g.map_cells8 = const_cast<uint8_t*>(k.map_cells8);
-  g.map_bytes = d_bytes;
-  g.map_spawn = const_cast<int4*>(k.map_spawn);
-  g.map_asm = const_cast<int4*>(k.map_asm);
-  g.map_nasm = const_cast<int*>(k.map_nasm);
-  g.map_chest = const_cast<int4*>(k.map_chest);
-  g.map_nchest = const_cast<int*>(k.map_nchest);
-  g.map_objcount = const_cast<float*>(k.map_objcount);
-  g.HW = k.HW; g.HW8 = k.HW8; g.A = k.A; g.NW = k.NW; g.NAmax = k.NAmax; g.NCmax = k.NCmax; g.n_cells = k.n_cells;
-  g.slot_state = d_state; g.inuse = d_inuse; g.gen = 0;
-  g.list = d_list; g.count = d_count; g.status = k.status;
   g.seed = seed;
-  h->d_inuse = d_inuse;
-  HIPCHK(mg_raise_lds_cap_mapgen(160 * 1024 - 4096));
   if (mg_refresh_impl(h, 1, 0)) return 1;
   HIPCHK(hipDeviceSynchronize());
   h->generated = true;
@@ -855,6 +870,53 @@ int mg_refresh_maps(mg_handle* h, int force, void* stream) {
   return 0;
 }
 
+int mg_write_map_slot(mg_handle* h, int slot, const uint8_t* cells, void* stream) {
+  if (!h || !cells) return fail("mg_write_map_slot: NULL argument");
+  if (!h->maps_set) return fail("mg_write_map_slot: call mg_set_maps first");
+  KArgs& k = h->k;
+  if (slot < 0 || slot >= k.P) return fail("mg_write_map_slot: slot out of range");
+  const int height = h->host_dims[0].x, width = h->host_dims[0].y;
+  for (const auto& d : h->host_dims)
+    if (d.x != height || d.y != width) return fail("mg_write_map_slot: the pool's maps differ in size");
+  if ((long long)height * width > MG_MAPGEN_MAX_CELLS) return fail("mg_write_map_slot: map too large for the slot builder");
+  // the same checks mg_set_maps makes, before anything is written
+  const MgConfig& c = h->cfg;
+  int n_agents = 0, n_asm = 0, n_chest = 0;
+  for (int i = 0; i < height * width; i++) {
+    const int code = cells[i];
+    if (code == 0) continue;
+    if ((size_t)code >= c.cells.size()) return fail("Unknown object type: cell code " + std::to_string(code) + " in the map for slot " + std::to_string(slot));
+    const int kind = c.cells[(size_t)code].kind;
+    n_agents += kind == MG_CELL_AGENT;
+    n_asm += kind == MG_CELL_ASSEMBLER;
+    n_chest += kind == MG_CELL_CHEST;
+  }
+  if (n_agents != c.A)
+    return fail("mg_write_map_slot: the map holds " + std::to_string(n_agents) + " agents but the config says num_agents = " + std::to_string(c.A));
+  if (n_asm > k.NAmax || n_chest > k.NCmax)
+    return fail("mg_write_map_slot: the map holds " + std::to_string(n_asm) + " assemblers / " + std::to_string(n_chest) +
+                " chests, the pool was sized for " + std::to_string(k.NAmax) + " / " + std::to_string(k.NCmax));
+  if (mg_use_device(h)) return 1;
+  if (!h->gen_ready && mg_mapgen_setup(h, height, width)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  MapGenArgs g = h->gen;
+  HIPCHK(hipMemcpyAsync(g.map_bytes + (size_t)slot * k.HW8, cells, (size_t)height * width, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));  // (`cells` is the caller's)
+  g.direct_slot = slot;
+  HIPCHK(hipMemsetAsync(g.count, 0, sizeof(int), st));
+  mg_launch_generate_maps(g, 1, st);
+  HIPCHK(hipGetLastError());
+  KArgs kt = h->kt;
+  kt.map_max_steps = h->k.map_max_steps;
+  kt.map_cfg = h->k.map_cfg;
+  kt.reset_envs = g.list;
+  kt.reset_maps = g.list;
+  kt.reset_count = g.count;
+  mg_launch_reset(kt, 1, h->lds_bytes, h->big, st);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int mg_get_map(mg_handle* h, int map_id, uint8_t* out, void* stream) {
   if (!h || !out) return fail("mg_get_map: NULL argument");
   if (!h->maps_set || !h->generated) return fail("mg_get_map: the pool was not made by mg_set_generated_maps");
@@ -867,7 +929,7 @@ int mg_get_map(mg_handle* h, int map_id, uint8_t* out, void* stream) {
 
 // Inspection helpers read the object lists of a map from the host mirror; a generated pool lives on the device only.
 static int mg_sync_lists(mg_handle* h, uint32_t map_id) {
-  if (!h->generated) return 0;
+  if (!h->generated && !h->gen_ready) return 0;  // (gen_ready: slots may have been rewritten by mg_write_map_slot)
   const KArgs& k = h->k;
   const size_t m = map_id;
   int na = 0, nc = 0;

@@ -36,6 +36,7 @@ struct MapGenArgs {
   int* count;  // [1]
   uint32_t* status;
   unsigned long long seed;
+  int direct_slot;  // >= 0: derive this one slot from the cell codes already in map_bytes (mg_write_map_slot), no drawing
 };
 
 void mg_launch_mark_maps(const DEnv* env, int E, uint32_t* inuse, uint32_t gen, hipStream_t st);

@@ -59,6 +59,7 @@ SYMBOLS = {
     "mg_set_generated_maps": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _i32p, _i32p, ct.c_int, ct.c_uint64]),
     "mg_refresh_maps": (ct.c_int, [_vp, ct.c_int, _vp]),
     "mg_get_map": (ct.c_int, [_vp, ct.c_int, _u8p, _vp]),
+    "mg_write_map_slot": (ct.c_int, [_vp, ct.c_int, _u8p, _vp]),
     "mg_map_dims": (ct.c_int, [_vp, ct.c_int, _i32p, _i32p]),
     "mg_reset": (ct.c_int, [_vp, _i32p, ct.c_int, _u32p, _i32p, _vp]),
     "mg_step": (ct.c_int, [_vp, _vp]),

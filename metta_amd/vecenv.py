@@ -427,11 +427,20 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
     (`mg_write_config_slot`), so the switch at an episode end happens on the device without waiting for the host; the
     price is one episode of lag in what the curriculum knows when it picks that task.  All tasks must share the shapes
     of the first task's configuration (agents, resources, actions, object types): rewards, limits, inventories,
-    protocols, attack costs, max_steps may vary -- what the reference's arena / navigation curricula bucket over."""
+    protocols, attack costs, max_steps may vary -- what the reference's arena / navigation curricula bucket over.
+
+    `task_maps=True`: the task's own `game.map_builder` builds the map of its episode on the host, as the reference's
+    simulator does at every episode start (simulator.py:264-267), and `mg_write_map_slot` puts it into the idle slot
+    together with the configuration -- for curricula that bucket over map parameters (object counts, terrain).  The
+    maps must have the size of the first task's; a task whose map does not fit is redrawn like any invalid task."""
 
     def __init__(self, curriculum, num_envs: int, maps: Optional[Sequence] = None, num_maps: int = 64, device: int = 0,
                  seed: int = 0, early_reset: bool = False, map_seed: int = 0, init_obs_passes: int = 2,
-                 device_maps: bool = False, map_refresh_every: Optional[int] = None):  # fmt: skip
+                 device_maps: bool = False, map_refresh_every: Optional[int] = None, task_maps: bool = False):  # fmt: skip
+        if task_maps and device_maps:
+            raise APIUsageError("task_maps builds maps on the host; device_maps draws them on the device: choose one")
+        self._task_maps = bool(task_maps)
+        self._map_rng = np.random.default_rng(map_seed + 1)
         self._curriculum = curriculum
         self._current_task = curriculum.get_task()  # (the reference draws one in its constructor too, :32)
         cfg = self._current_task.get_env_cfg()
@@ -462,6 +471,9 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
                 if len(self._blob_cache) > 4096:
                     self._blob_cache.clear()
                 self._blob_cache[key] = comp
+        if self._task_maps:  # before the configuration: a map that does not fit leaves the slot as it was
+            self.batch.write_map_slot(slot, task.get_env_cfg().game.map_builder.build(self._map_rng))
+            self.__dict__.setdefault("_groups_cache", {}).pop(slot, None)
         self.batch.write_config_slot(slot, comp)
         self._slot_task[slot] = task
 

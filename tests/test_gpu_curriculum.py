@@ -280,3 +280,62 @@ def test_curriculum_vecenv_on_a_device_generated_pool():
     assert len(cur.updates) >= 9 and all(len(s) >= 3 for s in maps_seen)
     b.check_errors()
     env.close()
+
+
+def test_curriculum_vecenv_builds_each_task_its_own_map():
+    """`task_maps=True`: a curriculum that buckets over map parameters (here the object counts of the arena builder).
+    Every episode plays the map its task's builder made (`mg_write_map_slot` into the idle slot) under the task's
+    configuration; bit-exact against the oracle built from that pair."""
+    import torch
+
+    from metta_amd.vecenv import CurriculumDeviceVecEnv
+    from oracle.mg_oracle import make_oracle_env
+
+    tasks = _tasks()
+    mines = [tasks[0].game.map_builder.objects["mine_red"], 1, 3]
+    assert mines[0] > 3
+    for t, n in zip(tasks, mines):
+        t.game.map_builder.objects = dict(t.game.map_builder.objects, mine_red=n)
+    instances = tasks[0].game.map_builder.device_spec().rooms.__len__()
+    cur = _Curriculum(tasks)
+    E, A = 3, 24
+    env = CurriculumDeviceVecEnv(cur, E, device=0, seed=11, map_seed=6, task_maps=True)
+    env.stats_every = 1
+    env.async_reset()
+    slot_task = [(1 + s) % 3 for s in range(2 * E)]
+    comps = [compile_game(t, init_obs_passes=2) for t in tasks]
+    mine_code = comps[0].cell_code["mine_red"]
+    slot_of = list(range(E))
+    b = env.batch
+
+    def start(e, s):
+        m = np.array(b.map_pool[s])
+        assert int((m == mine_code).sum()) == mines[slot_task[s]] * instances, "the slot holds its task's map"
+        return make_oracle_env(comps[slot_task[s]], m, 11 + e), m.tobytes()
+
+    oras, seen = [], [set() for _ in range(E)]
+    for e, s in enumerate(slot_of):
+        o, key = start(e, s)
+        oras.append(o)
+        seen[e].add(key)
+    next_draw = 1 + 2 * E
+    g = torch.Generator().manual_seed(2)
+    for t in range(1, 130):
+        o, r, d, tr, ta, info, ids, mask = env.recv()
+        obs = o.cpu().numpy().reshape(E, A, -1, 3)
+        for e in range(E):
+            assert np.array_equal(obs[e], oras[e].obs), f"step {t} env {e}"
+        acts = torch.randint(0, 5, (E, A), generator=g, dtype=torch.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                s = slot_of[e]
+                slot_task[s] = next_draw % 3
+                next_draw += 1
+                s = slot_of[e] = (s + E) % (2 * E)
+                oras[e], key = start(e, s)
+                seen[e].add(key)
+            oras[e].step(acts[e].numpy())
+        env.send(acts.reshape(-1).cuda())
+    assert len(cur.updates) >= 9 and all(len(s) >= 3 for s in seen), "every episode had a map of its own"
+    b.check_errors()
+    env.close()

@@ -263,3 +263,104 @@ def test_vecenv_with_device_maps_refreshes_without_host_syncs():
         assert len(seen[e]) == 5, "five episodes, five maps"
     env.batch.check_errors()
     env.close()
+
+
+@pytest.mark.parametrize("path_env", [{}, {"MG_FORCE_GENERAL": "1"}], ids=["fused", "general"])
+def test_host_built_maps_written_into_idle_slots_vs_oracle(path_env, monkeypatch):
+    """`mg_write_map_slot`: the reference's per-episode `map_builder.build()` (simulator.py:264-267) for maps the host
+    builds.  An uploaded pool of 2E slots, stride E; before every episode the idle twin slot receives another of the
+    reference's 64 MapGen maps.  Bit-exact parity with the oracle built on that map proves that the slot's derived
+    entries (object ids, spawn / assembler / chest lists, counts) and its episode-start template match the bytes."""
+    from metta_amd.batch import MettaGridBatch
+    from oracle.mg_oracle import make_oracle_env
+
+    for k, v in path_env.items():
+        monkeypatch.setenv(k, v)
+    cfg = make_arena(24)
+    cfg.game.max_steps = 20
+    comp = compile_game(cfg, init_obs_passes=2)
+    ref = [comp.encode_map(m) for m in load_map_pool()]
+    E, A = 3, 24
+    seeds, cur_map = [31, 32, 33], [0, 1, 2]
+    b = MettaGridBatch(cfg, E, ref[: 2 * E], device=0, seeds=seeds, map_ids=cur_map)
+    b.set_auto_reset(True, E)
+    slot_map = {m: ref[m] for m in range(2 * E)}
+    nxt = 2 * E
+    oras = [make_oracle_env(comp, slot_map[m], s) for s, m in zip(seeds, cur_map)]
+    _compare_step(b, oras, 0, A)
+    rs = np.random.RandomState(8)
+    for t in range(1, 110):
+        if t % 20 == 10:  # mid-episode: fill every idle slot with a map not played yet
+            for e in range(E):
+                idle = (cur_map[e] + E) % (2 * E)
+                b.write_map_slot(idle, ref[nxt % len(ref)])
+                slot_map[idle] = ref[nxt % len(ref)]
+                assert np.array_equal(b.map_pool[idle], slot_map[idle])
+                nxt += 1
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + E) % (2 * E)
+                oras[e] = make_oracle_env(comp, slot_map[cur_map[e]], seeds[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+        if t % 35 == 0:
+            _compare_state(b, oras, t)
+    assert nxt == 2 * E + 5 * E
+    b.check_errors()
+    b.close()
+
+
+def test_write_map_slot_on_a_generated_pool_and_its_errors():
+    from metta_amd.batch import MettaGridBatch
+    from oracle.mg_oracle import make_oracle_env
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 12
+    comp = compile_game(cfg, init_obs_passes=2)
+    spec = cfg.game.map_builder.device_spec()
+    ref = [comp.encode_map(m) for m in load_map_pool()]
+    b = _gen_batch(cfg, 1, spec, 2, seed=2, seeds=[5], map_ids=[0])
+    b.set_auto_reset(True, 1)
+    b.write_map_slot(1, ref[7])  # the slot the environment enters next
+    assert np.array_equal(b.get_map(1), ref[7])
+    # a written slot counts as fresh: a refresh leaves it alone until an episode has used it
+    b.refresh_maps()
+    assert np.array_equal(b.get_map(1), ref[7])
+    ora = make_oracle_env(comp, b.get_map(0), 5)
+    rs = np.random.RandomState(1)
+    cur = 0
+    for t in range(1, 30):
+        acts = rs.randint(0, 5, size=(1, 24)).astype(np.int32)
+        if ora.terminals.all() or ora.truncations.all():
+            cur ^= 1
+            ora = make_oracle_env(comp, b.get_map(cur), 5)
+        ora.step(acts[0])
+        b.step(acts.reshape(-1))
+        _compare_step(b, [ora], t, 24)
+    bad = ref[3].copy()
+    bad[np.isin(bad, [c + 1 for c, k in enumerate(comp.cell_kinds) if k == 2])] = 0
+    with pytest.raises(RuntimeError, match="holds 0 agents but the config says num_agents = 24"):
+        b.write_map_slot(0, bad)
+    crowded = ref[3].copy()
+    crowded[crowded == 0] = [c + 1 for c, k in enumerate(comp.cell_kinds) if k == 3][0]
+    with pytest.raises(RuntimeError, match="the pool was sized for"):
+        b.write_map_slot(0, crowded)
+    with pytest.raises(RuntimeError, match="slot out of range"):
+        b.write_map_slot(2, ref[3])
+    with pytest.raises(RuntimeError, match="the pool's slots are"):
+        b.write_map_slot(0, ref[3][:40])
+    unknown = ref[3].copy()
+    unknown[1, 1] = 200
+    with pytest.raises(RuntimeError, match="Unknown object type"):
+        b.write_map_slot(0, unknown)
+    b.check_errors()
+    b.close()
+    # pools of mixed sizes have no slot to write to
+    small = np.zeros((20, 20), np.uint8)
+    small[2:8, 2:6] = comp.cell_code["agent.agent"]
+    b2 = MettaGridBatch(cfg, 1, [ref[0], small], device=0)
+    with pytest.raises(RuntimeError, match="differ in size"):
+        b2.write_map_slot(0, ref[1])
+    b2.close()
