@@ -199,6 +199,14 @@ int mg_chest_state(mg_handle* h, int env, int32_t* out, int max_chests, int32_t*
 int mg_agent_state(mg_handle* h, int env, int32_t* out, void* stream);
 int mg_num_assemblers(mg_handle* h, int env);
 int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream);
+
+/* The Clipper's view of environment `env` (packages/mettagrid/cpp/include/mettagrid/systems/clipper.hpp:19-30:
+ * `assembler_infection_weight`, `length_scale`): weights[mg_num_assemblers(h, env)] = infection weight of every assembler
+ * in map (row-major) order, 0 for clip-immune ones; *length_scale = the scale in use (the configured one, or the one
+ * derived from the map's sparsity, clipper.hpp:65-98).  Inspection / parity tests; synchronises `stream`.  An
+ * assembler's clipped state is column 4 of mg_assembler_state: 0 = no, 1 = clipped without an unclipping protocol
+ * (it started clipped and no clipper exists), 2 + k = clipped by the clipper with its k-th unclipping protocol. */
+int mg_clipper_state(mg_handle* h, int env, uint32_t* weights, int32_t* length_scale, void* stream);
 int mg_env_info(mg_handle* h, int env, uint32_t* current_step, int32_t* map_id, uint32_t* seed, uint32_t* episodes,
                 void* stream);
 

@@ -409,6 +409,17 @@ class MettaGridBatch:
             self._check(self.L.mg_assembler_state(self._h, env, _p(out, ct.c_int32), self._stream()))
         return out[:n]
 
+    def clipper_state(self, env: int):
+        """(length scale in use, infection weight of every assembler of `env`): the Clipper's `length_scale` and
+        `assembler_infection_weight` (clipper.hpp:19-30)."""
+        n = self.L.mg_num_assemblers(self._h, env)
+        if n < 0:
+            raise RuntimeError("mg_num_assemblers failed")
+        w = np.zeros(max(n, 1), np.uint32)
+        ls = ct.c_int32()
+        self._check(self.L.mg_clipper_state(self._h, env, _p(w, ct.c_uint32), ct.byref(ls), self._stream()))
+        return int(ls.value), w[:n]
+
     def chest_state(self, env: int) -> np.ndarray:
         """[n][5 + 2R]: r, c, chest config index, object id, n_items, (item, amount) in inventory order."""
         n = ct.c_int32()
@@ -484,7 +495,10 @@ class MettaGridBatch:
                         uses_count=int(np.uint32(a[7])),
                         max_uses=int(getattr(ocfg, "max_uses", 0)),
                         allow_partial_usage=bool(getattr(ocfg, "allow_partial_usage", False)),
-                        protocols=[dict(p) for p in (c.assembler_protocol_listing or {}).get(c.cell_names[code - 1], [])],
+                        # (a clipped station lists its unclipping protocols instead, mettagrid_c.cpp:872-873)
+                        protocols=[dict(p) for p in (c.assembler_protocol_listing or {}).get(c.cell_names[code - 1], [])]
+                        if int(a[4]) == 0
+                        else [dict(c.unclip_protocol_listing[int(a[4]) - 2])] if int(a[4]) >= 2 else [],
                     )
                 elif kind == 4:  # chest
                     ch = chs[n_chest]

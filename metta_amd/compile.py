@@ -32,7 +32,7 @@ from metta_amd.id_map import FIXED_FEATURES, encoder_num_inventory_tokens
 from metta_amd.umap import order_from_inserts, order_from_pydict, std_hash_string
 
 MG_BLOB_MAGIC = 0x4D474231
-MG_BLOB_VERSION = 4
+MG_BLOB_VERSION = 5
 
 ACT_NOOP, ACT_MOVE, ACT_CHANGE_VIBE = 0, 1, 2
 CELL_WALL, CELL_AGENT, CELL_ASSEMBLER, CELL_CHEST = 1, 2, 3, 4
@@ -102,6 +102,7 @@ class CompiledGame:
     game_slot_names: list[str]
     extra: dict[str, Any] = field(default_factory=dict)
     assembler_protocol_listing: dict = field(default_factory=dict)  # assembler object name -> `protocols` of grid_objects
+    unclip_protocol_listing: list = field(default_factory=list)  # the clipper's unclipping protocols, same form
 
     @property
     def cell_code(self) -> dict[str, int]:
@@ -146,11 +147,8 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     stats) are computed once by the constructor and once more by `set_buffers`; 1 reproduces a
     bare `MettaGrid(cfg, map, seed)`."""
     game = cfg.game if isinstance(cfg, MettaGridConfig) else cfg
-    if game.clipper is not None:
-        raise NotImplementedError(
-            "clipper: iteration over std::set<Assembler*> is pointer-ordered in the reference (not reproducible); "
-            "out of scope for the step path (SURVEY §8a A19)"
-        )
+    if game.clipper is not None and not game.clipper.unclipping_protocols:
+        raise RuntimeError("Clipper config provided but unclipping_protocols is empty")  # mettagrid_c.cpp:145-147
     # collectives (mettagrid_c_config.py:544-575; BIND/mettagrid_c.cpp:95-128): only what the step path can observe --
     # the statistics `Agent::compute_stat_rewards` reads through `getCollective()` (agent.cpp:115-117)
     coll_id = {c.name: i for i, c in enumerate(game.collectives)}
@@ -516,6 +514,44 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     w.i(len(game.collectives))
     for cc in game.collectives:
         w.kv(_ordered_items({rid[k]: int(v) for k, v in cc.inventory.initial.items() if k in rid}))
+    # clipper (mettagrid_c_config.py:506-539; systems/clipper.hpp): the unclipping protocols in list order (NOT
+    # reversed, unlike an assembler's), each with the key `build_protocol_map` files it under (assembler.hpp:326-349)
+    clip = game.clipper
+    unclip_protocol_listing: list = []
+    w.i(0 if clip is None else 1)
+    if clip is not None:
+        w.i(clip.length_scale, clip.scaled_cutoff_distance, clip.clip_period, len(clip.unclipping_protocols))
+        shapes = set()
+        for pc in clip.unclipping_protocols:
+            for v in pc.vibes:
+                if v not in vid:
+                    raise ValueError(f"Unknown vibe name '{v}' in clipper unclipping_protocols")
+            vids = sorted(vid[v] for v in pc.vibes)
+            ins = _ordered_items({rid[k]: int(v) for k, v in pc.input_resources.items()})
+            outs = _ordered_items({rid[k]: int(v) for k, v in pc.output_resources.items()})
+            w.i(pc.min_agents, pc.cooldown)
+            w.list(vids)
+            w.kv(ins)
+            w.kv(outs)
+            w.list(order_from_inserts([k for k, _ in ins]))
+            w.list(order_from_inserts([k for k, _ in outs]))
+            key = 0
+            for v in vids:
+                key = ((key << 8) | v) & ((1 << 64) - 1)
+            w.i(key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF)
+            shapes.add((key, pc.min_agents, sum(v > 0 for _, v in ins), sum(v > 0 for _, v in outs)))
+            unclip_protocol_listing.append({"inputs": dict(ins), "outputs": dict(outs), "cooldown": pc.cooldown,
+                                            "min_agents": pc.min_agents, "vibes": list(vids)})  # fmt: skip
+        # An assembler that starts clipped draws its unclipping protocol from the environment's seed when the Clipper is
+        # built (clipper.hpp:107-110,186-193).  The episode-start templates are per map, not per seed: they hold the
+        # `tokens_*` statistics of the initial observations, which count that protocol's input / output tokens.
+        if (len(shapes) > 1 and game.protocol_details_obs
+                and any(o.start_clipped and not o.clip_immune for o in assemblers)):  # fmt: skip
+            raise NotImplementedError(
+                "clipper: assemblers that start clipped, with unclipping protocols that differ in vibes, min_agents or "
+                "the number of non-zero inputs / outputs, and protocol_details_obs: the initial token statistics would "
+                "depend on the seed (per-map episode templates cannot hold them)"
+            )
     w.i(len(agent_slot_names[0]) if agent_slot_names else 0, len(game_slot_names))
     w.i(MG_BLOB_MAGIC)
 
@@ -542,6 +578,7 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
         tag_names=tag_names,
         object_type_names=object_type_names,
         assembler_protocol_listing=assembler_protocol_listing,
+        unclip_protocol_listing=unclip_protocol_listing,
         feature_names={f.id: f.name for f in feats},
         agent_slot_names=agent_slot_names,
         game_slot_names=game_slot_names,

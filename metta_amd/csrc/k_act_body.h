@@ -21,6 +21,7 @@
 //
 // BIG (map tile + records do not fit LDS: 256 x 256 x 1024 agents): grid tile and agent records are used in place in
 // HBM (L2); LDS holds the claim table, order / rank, the RNG window and the per-use scratch pool.
+#define MG_WITH_CLIPPER  // (mg_restart_env rebuilds the environment's clipper)
 #include "mg_kernels.h"
 
 #define MG_ACT_MAX_THREADS 1024

@@ -1,4 +1,5 @@
 // k_reset.hip -- see mg_kernels.h / DESIGN.md section 4
+#define MG_WITH_CLIPPER
 #include "mg_kernels.h"
 
 // Reset kernel: `MettaGrid` construction + `_init_buffers` for the listed environments.
@@ -41,8 +42,24 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   __syncthreads();
   mg_encode_all(a, l, e, 0, nullptr, true, tid, nt);
   __syncthreads();
+  int passes = a.dc[DC_INIT_PASSES];
+  if (a.clip_w && a.dc[DC_CLIPPER]) {
+    // The reference builds its Clipper after the constructor's own observation pass (mettagrid_c.cpp:139-154): the
+    // stations that start clipped show no protocol tokens in that pass, and the one their clipper drew in the passes
+    // after it (set_buffers).
+    if (tid == 0) mg_token_stats(a, l, 1);
+    __syncthreads();
+    mg_clipper_init(a, a.dc, l.as, e, (int)env.map_id, a.H, a.W, tid, nt);
+    passes -= 1;
+    if (passes > 0) {
+      mg_build_tokens(a, l, (int)env.map_id, 0, tid, nt);
+      __syncthreads();
+      mg_encode_all(a, l, e, 0, nullptr, true, tid, nt);
+      __syncthreads();
+    }
+  }
   if (tid == 0) {
-    mg_token_stats(a, l, a.dc[DC_INIT_PASSES]);
+    mg_token_stats(a, l, passes);
     float* gs_ = a.gstats + (size_t)e * a.SG;
     gs_[0] = l.tokacc[0];
     gs_[1] = l.tokacc[1];

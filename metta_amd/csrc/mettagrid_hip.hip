@@ -248,12 +248,15 @@ static int mg_check_supported(const MgConfig& c, const char* who) {
   for (const auto& a : c.assemblers)
     for (const auto& p : a.protocols)
       if (p.vibes.size() > 8) return fail(std::string(who) + ": protocols with more than 8 vibes are not supported");
+  for (const auto& p : c.unclip)
+    if (p.vibes.size() > 8) return fail(std::string(who) + ": protocols with more than 8 vibes are not supported");
+  if (c.clipper && (c.clip_cutoff < 0 || c.clip_cutoff > 30)) return fail(std::string(who) + ": clipper scaled_cutoff_distance must be 0..30");
   return 0;
 }
 
 // fast (wave-parallel) act kernel eligibility: see mg_act_fast_kernel
 static bool mg_fast_eligible(const MgConfig& c) {
-  bool ok = c.A <= 64 && c.regen_interval == 0 && !mg_has_damage(c) && c.chests.empty();
+  bool ok = c.A <= 64 && c.regen_interval == 0 && !mg_has_damage(c) && c.chests.empty() && !c.clipper;
   for (int v : c.vibe_handler) ok = ok && v == 0;
   for (int hnd = 0; hnd < MG_NUM_HANDLERS; hnd++) ok = ok && c.handler[hnd].required.empty() && c.handler[hnd].consumed.empty();
   return ok;
@@ -275,6 +278,8 @@ static void mg_token_strides(const MgConfig& c, int ts[4]) {
   for (const auto& a : c.assemblers) {
     int io = 0;
     for (const auto& p : a.protocols) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
+    if (!a.clip_immune)  // a clipped station shows its unclipping protocol instead
+      for (const auto& p : c.unclip) io = std::max(io, (int)p.inputs.size() + (int)p.outputs.size());
     TSS = std::max(TSS, 3 + io + (int)a.tags.size() + 1);
   }
   for (const auto& ch : c.chests) TSC = std::max(TSC, 1 + c.R * c.n_inv_tokens + (int)ch.tags.size());
@@ -295,7 +300,7 @@ static int dalloc(mg_handle* h, T** p, size_t n, bool map_alloc = false) {
 extern "C" {
 
 const char* mg_last_error(void) { return g_err.c_str(); }
-const char* mg_version(void) { return MGD_MAX_R == 16 ? "mettagrid_hip 0.1 (gfx950; blob v4; 16 resources)" : "mettagrid_hip 0.1 (gfx950; blob v4; 32 resources)"; }
+const char* mg_version(void) { return MGD_MAX_R == 16 ? "mettagrid_hip 0.1 (gfx950; blob v5; 16 resources)" : "mettagrid_hip 0.1 (gfx950; blob v5; 32 resources)"; }
 int mg_max_resources(void) { return MGD_MAX_R; }
 
 int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int device_id, mg_handle** out) {
@@ -365,6 +370,10 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &k.env, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.mt, (size_t)num_envs * 624)) return 1;
   if (dalloc(h.get(), &k.mt_init, (size_t)num_envs * 624)) return 1;
+  if (c.clipper) {  // (the weights are sized with the pool: mg_set_maps)
+    if (dalloc(h.get(), &k.clip_mt, (size_t)num_envs * 624)) return 1;
+    if (dalloc(h.get(), &k.clip_state, (size_t)num_envs)) return 1;
+  }
   if (dalloc(h.get(), &k.agents, N)) return 1;
   if (dalloc(h.get(), &k.astats, N * k.SA)) return 1;
   if (dalloc(h.get(), &k.atouched, N * k.TW)) return 1;
@@ -654,6 +663,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (dalloc(h, &h->d_map_cfg, (size_t)num_maps, true)) return 1;
     k.map_cfg = h->d_map_cfg;
   }
+  k.clip_w = nullptr;
+  if (c.clipper && dalloc(h, &k.clip_w, (size_t)h->E * (size_t)std::max(NAmax, 1), true)) return 1;
   // ---- episode-start templates: run the reset kernel once per map into template buffers ------------------
   {
     const size_t P = (size_t)num_maps, PA = P * c.A;
@@ -675,6 +686,11 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (dalloc(h, &kt.env, P, true)) return 1;
     if (dalloc(h, &kt.mt, P * 624, true)) return 1;
     kt.mt_init = nullptr;
+    if (c.clipper) {  // the templates' own clipper: what it draws is redrawn per environment at a restart
+      if (dalloc(h, &kt.clip_mt, P * 624, true)) return 1;
+      if (dalloc(h, &kt.clip_state, P, true)) return 1;
+      if (dalloc(h, &kt.clip_w, P * (size_t)k.NAmax, true)) return 1;
+    }
     kt.chests = t_chests;
     kt.agents = t_agents; kt.asms = t_asms; kt.astats = t_astats; kt.atouched = t_atouched;
     kt.gstats = t_gstats; kt.gtouched = t_gtouched;
@@ -1041,6 +1057,7 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
     if (v.fid[i] != c.fid[i]) return differs("the observation feature ids");
   if (v.fid_inv != c.fid_inv || v.fid_in != c.fid_in || v.fid_out != c.fid_out) return differs("the observation feature ids");
   if (v.init_obs_passes != c.init_obs_passes) return differs("init_obs_passes");
+  if ((v.clipper != 0) != (c.clipper != 0)) return differs("having a clipper (its buffers belong to the handle)");
   if (mg_has_damage(v) && !mg_has_damage(c)) return differs("damage (the RNG window was sized without it)");
   int ts[4];
   mg_token_strides(v, ts);
@@ -1206,6 +1223,7 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
         mg_launch_uses(kg, n, h->lds_uses, h->dc_lds, st);
       } else {
         mg_launch_act(kg, n, h->lds_act, h->dc_lds, h->big, st);
+        if (kg.clip_w) mg_launch_clipper(kg, n, st);
       }
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
       mg_launch_obs(kg, n, h->lds_obs, h->dc_lds, h->big, st);
@@ -1476,6 +1494,25 @@ int mg_assembler_state(mg_handle* h, int env, int32_t* out, void* stream) {
     o[0] = lst[i].x; o[1] = lst[i].y; o[2] = lst[i].z; o[3] = lst[i].w; o[4] = (int32_t)as[i].clipped;
     o[5] = (int32_t)as[i].cooldown_end; o[6] = (int32_t)as[i].cooldown_duration; o[7] = (int32_t)as[i].uses_count;
   }
+  return 0;
+}
+
+int mg_clipper_state(mg_handle* h, int env, uint32_t* weights, int32_t* length_scale, void* stream) {
+  if (!h || !weights || !length_scale) return fail("mg_clipper_state: NULL argument");
+  if (env < 0 || env >= h->E) return fail("mg_clipper_state: environment id out of range");
+  if (!h->k.clip_w) return fail("mg_clipper_state: the configuration has no clipper (or mg_set_maps has not run)");
+  HIPCHK(hipSetDevice(h->device));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  const KArgs& k = h->k;
+  uint2 st;
+  HIPCHK(hipMemcpy(&st, k.clip_state + env, sizeof(st), hipMemcpyDeviceToHost));
+  DEnv d;
+  HIPCHK(hipMemcpy(&d, k.env + env, sizeof(d), hipMemcpyDeviceToHost));
+  int n = 0;
+  HIPCHK(hipMemcpy(&n, k.map_nasm + d.map_id, 4, hipMemcpyDeviceToHost));
+  if (n > 0) HIPCHK(hipMemcpy(weights, k.clip_w + (size_t)env * k.NAmax, (size_t)n * 4, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) weights[i] &= 0x7FFFFFFFu;  // (bit 31 is the kernel's own bookkeeping)
+  *length_scale = (int32_t)st.y;
   return 0;
 }
 

@@ -18,7 +18,7 @@
 #include <vector>
 
 #define MG_BLOB_MAGIC 0x4D474231  // 'MGB1'
-#define MG_BLOB_VERSION 4
+#define MG_BLOB_VERSION 5
 
 enum MgActionKind { MG_ACT_NOOP = 0, MG_ACT_MOVE = 1, MG_ACT_CHANGE_VIBE = 2 };
 enum MgCellKind { MG_CELL_EMPTY = 0, MG_CELL_WALL = 1, MG_CELL_AGENT = 2, MG_CELL_ASSEMBLER = 3, MG_CELL_CHEST = 4 };
@@ -162,6 +162,10 @@ struct MgTransferEffect {
 
 struct MgConfig {
   std::vector<MgKVList> collective_initial;  // per collective: (item, amount)
+  // Clipper (systems/clipper.hpp:14-46, clipper_config.hpp:11-27)
+  int32_t clipper = 0, clip_length_scale = 0, clip_cutoff = 0, clip_period = 0;
+  std::vector<MgProtocol> unclip;     // unclipping protocols, configuration order
+  std::vector<uint64_t> unclip_key;   // sorted vibes, 8 bits each (assembler.hpp:326-331)
   int32_t R = 0, A = 0, obs_w = 0, obs_h = 0, T = 0, token_base = 256, max_steps = 0, episode_truncates = 0;
   int32_t g_completion = 1, g_last_action = 1, g_last_reward = 1, g_compass = 0, g_goal = 0;
   int32_t protocol_details_obs = 1, regen_interval = 0, init_obs_passes = 1, n_vibes = 0, n_group_names = 0;
@@ -341,6 +345,21 @@ struct MgConfig {
       int32_t nc = r.i32();
       c.collective_initial.resize((size_t)nc);
       for (auto& kv : c.collective_initial) kv = r.kvlist();
+    }
+    c.clipper = r.i32();
+    if (c.clipper) {
+      c.clip_length_scale = r.i32(); c.clip_cutoff = r.i32(); c.clip_period = r.i32();
+      int32_t np = r.i32();
+      if (np < 1) throw std::runtime_error("Clipper config provided but unclipping_protocols is empty");
+      c.unclip.resize((size_t)np);
+      c.unclip_key.resize((size_t)np);
+      for (size_t i = 0; i < (size_t)np; i++) {
+        MgProtocol& p = c.unclip[i];
+        p.min_agents = r.i32(); p.cooldown = r.i32(); p.vibes = r.list(); p.inputs = r.kvlist(); p.outputs = r.kvlist();
+        p.inputs_scaled = r.list(); p.outputs_scaled = r.list();
+        uint32_t lo = (uint32_t)r.i32(), hi = (uint32_t)r.i32();
+        c.unclip_key[i] = ((uint64_t)hi << 32) | lo;
+      }
     }
     c.n_agent_slots = r.i32();
     c.n_game_slots = r.i32();

@@ -22,7 +22,11 @@ enum MgDc {
   DC_OFF_VIBE_HANDLER = DC_OFF_HANDLERS + 6, DC_OFF_ATK_CONSUMED, DC_OFF_ATK_DEFENSE, DC_OFF_ATK_ARMOR,
   DC_OFF_ATK_WEAPON, DC_OFF_ATK_ACTOR, DC_OFF_ATK_TARGET, DC_OFF_ATK_LOOT, DC_OFF_ATK_VIBE_BONUS,
   DC_OFF_VIBE_RESOURCE, DC_OFF_XFER_REQUIRED, DC_OFF_XFER_EFFECTS, DC_OFF_GROUPS, DC_OFF_WALLS, DC_OFF_ASMS,
-  DC_OFF_PATTERN, DC_OFF_CELLS, DC_OFF_CHESTS, DC_HEADER_WORDS
+  DC_OFF_PATTERN, DC_OFF_CELLS, DC_OFF_CHESTS,
+  // Clipper (systems/clipper.hpp): present flag, configured length scale (0 = from the map's sparsity), cutoff in units
+  // of the length scale, clip period, and the unclipping protocols as (protocol record, key lo, key hi) triples
+  DC_CLIPPER, DC_CLIP_LENGTH, DC_CLIP_CUTOFF, DC_CLIP_PERIOD, DC_N_UNCLIP, DC_OFF_UNCLIP,
+  DC_HEADER_WORDS
 };
 // group record
 enum MgGr {
@@ -275,6 +279,26 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
     int o = b.reserve((int)table.size());
     for (size_t i = 0; i < table.size(); i++) b.w[(size_t)o + i] = table[i];
     H(DC_OFF_ASMS) = o;
+  }
+  {  // clipper: the protocol a clipped station offers is one of these (clipper.hpp:186-193, assembler.hpp:411-421)
+    H(DC_CLIPPER) = c.clipper; H(DC_CLIP_LENGTH) = c.clip_length_scale; H(DC_CLIP_CUTOFF) = c.clip_cutoff;
+    H(DC_CLIP_PERIOD) = c.clip_period; H(DC_N_UNCLIP) = (int32_t)c.unclip.size();
+    std::vector<int32_t> tb;
+    for (size_t i = 0; i < c.unclip.size(); i++) {
+      const MgProtocol& p = c.unclip[i];
+      int32_t pr[PR_WORDS];
+      pr[PR_MIN_AGENTS] = p.min_agents; pr[PR_COOLDOWN] = p.cooldown; pr[PR_OFF_VIBES] = b.put_list(p.vibes);
+      pr[PR_OFF_IN] = b.put_kv(p.inputs); pr[PR_OFF_OUT] = b.put_kv(p.outputs);
+      pr[PR_OFF_IN_S] = b.put_list(p.inputs_scaled); pr[PR_OFF_OUT_S] = b.put_list(p.outputs_scaled);
+      int o = b.reserve(PR_WORDS);
+      for (int q = 0; q < PR_WORDS; q++) b.w[(size_t)o + (size_t)q] = pr[q];
+      tb.push_back(o);
+      tb.push_back((int32_t)(uint32_t)(c.unclip_key[i] & 0xFFFFFFFFull));
+      tb.push_back((int32_t)(uint32_t)(c.unclip_key[i] >> 32));
+    }
+    int o = b.reserve((int)tb.size());
+    for (size_t i = 0; i < tb.size(); i++) b.w[(size_t)o + i] = tb[i];
+    H(DC_OFF_UNCLIP) = o;
   }
   H(DC_OBS_WORDS) = (int32_t)((b.w.size() + 3) & ~(size_t)3);
   while (b.w.size() % 4) b.w.push_back(0);

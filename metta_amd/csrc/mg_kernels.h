@@ -98,6 +98,12 @@ struct KArgs {
   const uint32_t* reset_seeds;
   const int* reset_maps;
   const int* reset_count;  // or null: blocks at or past *reset_count leave at once (device-side list lengths)
+  // Clipper (systems/clipper.hpp), null without one: its own std::mt19937 per environment (a copy of the engine as
+  // seeded, mettagrid_c.cpp:153), (next state word, length scale) and the infection weight of every station
+  // (bit 31: the clipper clipped it and has not seen it unclipped yet)
+  uint32_t* clip_mt;   // [E][624]
+  uint2* clip_state;   // [E]
+  uint32_t* clip_w;    // [E][NAmax]
 };
 
 struct Lds {
@@ -998,6 +1004,104 @@ __device__ inline void mg_stage_rng(const KArgs& a, const Lds& l, int e, uint32_
   }
 }
 
+#ifdef MG_WITH_CLIPPER
+// ---- Clipper (systems/clipper.hpp:14-239) -------------------------------------------------------------------------------
+// Its sets of assemblers are std::set<Assembler*>, walked in pointer order (clipper.hpp:24-26,207-229); here: station
+// index = creation order, the order of a fresh process of the reference (oracle/mg_oracle.cpp, tests/golden/
+// feature_119.. fixtures).  Adjacency lists are not kept: j is adjacent to i iff both are members (not clip-immune),
+// i != j and their L_inf distance is within cutoff * length_scale; then the weight is >= 1.  The border set is
+// "member, not clipped, weight > 0" (a zero-weight member can never be picked).  All of it runs on one thread: one
+// draw per step, a clip event every `clip_period` steps.
+struct ClipRng {  // std::mt19937 one word at a time: the same sequence as twisting whole blocks
+  uint32_t* mt;
+  uint32_t idx;
+  __device__ inline uint32_t next() {
+    const uint32_t i = idx, i1 = i + 1 == 624 ? 0 : i + 1, im = i + 397 >= 624 ? i + 397 - 624 : i + 397;
+    const uint32_t y = mt_mix(mt[i], mt[i1], mt[im]);
+    mt[i] = y;
+    idx = i1;
+    return mt_temper(y);
+  }
+  __device__ inline uint32_t bounded(uint32_t range) {  // uniform_int_dist.h:258-269
+    unsigned long long product = (unsigned long long)next() * range;
+    uint32_t low = (uint32_t)product;
+    if (low < range) {
+      const uint32_t threshold = (0u - range) % range;
+      while (low < threshold) {
+        product = (unsigned long long)next() * range;
+        low = (uint32_t)product;
+      }
+    }
+    return (uint32_t)(product >> 32);
+  }
+};
+__device__ inline bool mg_clip_member(const int* dc, const int4* info, int i) {
+  return asm_rec(dc, info[i].z)[AR_CLIP_IMMUNE] == 0;
+}
+// infection_weight (clipper.hpp:113-128) of two adjacent stations, 0 = not adjacent (clipper.hpp:156-169)
+__device__ inline uint32_t mg_clip_weight(const int4 a, const int4 b, uint32_t ls, uint32_t cutoff) {
+  const int dr = a.x > b.x ? a.x - b.x : b.x - a.x, dcl = a.y > b.y ? a.y - b.y : b.y - a.y;
+  const uint32_t dist = (uint32_t)(dr > dcl ? dr : dcl);
+  if (dist > cutoff * ls) return 0u;
+  return 1u << (cutoff - dist / ls);
+}
+// clip_assembler (clipper.hpp:174-194) + become_clipped (assembler.hpp:411-421)
+__device__ inline void mg_clip_assembler(const int* dc, DAsm* as, const int4* info, int nasm, uint32_t* w, uint32_t ls,
+                                         ClipRng& rng, int i, uint32_t step) {
+  const uint32_t cutoff = (uint32_t)dc[DC_CLIP_CUTOFF];
+  if (dc[DC_CLIP_PERIOD] > 0)  // (compute_adjacencies only runs for an active clipper, clipper.hpp:101-105)
+    for (int j = 0; j < nasm; j++) {
+      if (j == i || !mg_clip_member(dc, info, j)) continue;
+      const uint32_t wt = mg_clip_weight(info[i], info[j], ls, cutoff);
+      if (wt) w[j] += wt;
+    }
+  const uint32_t k = rng.bounded((uint32_t)dc[DC_N_UNCLIP]);
+  as[i].clipped = 2u + k;
+  as[i].cooldown_end = step;
+  as[i].cooldown_duration = 0;
+  w[i] |= 0x80000000u;
+}
+// The Clipper's constructor (clipper.hpp:35-111) for environment e on map `map_id`: a fresh engine, zero weights, the
+// length scale, and the stations that start clipped, in object order.  All threads; `as` = the station records
+// (LDS or HBM), `dc` = the configuration the map plays.
+__device__ inline void mg_clipper_init(const KArgs& a, const int* dc, DAsm* as, int e, int map_id, int H, int W, int tid,
+                                       int nt) {
+  if (!a.clip_w || !dc[DC_CLIPPER]) return;  // block-uniform
+  uint32_t* cm = a.clip_mt + (size_t)e * 624;
+  const uint32_t* src = (a.mt_init ? a.mt_init : a.mt) + (size_t)e * 624;  // std::mt19937(seed), nothing drawn yet
+  for (int i = tid; i < 624; i += nt) cm[i] = src[i];
+  uint32_t* w = a.clip_w + (size_t)e * a.NAmax;
+  for (int i = tid; i < a.NAmax; i += nt) w[i] = 0u;
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {
+    const int nasm = a.map_nasm[map_id];
+    const int4* info = a.map_asm + (size_t)map_id * a.NAmax;
+    int members = 0;
+    for (int i = 0; i < nasm; i++) members += mg_clip_member(dc, info, i) ? 1 : 0;
+    int ls = dc[DC_CLIP_LENGTH];
+    if (ls <= 0 && members > 0) {  // clipper.hpp:65-98: from the sparsity of the stations
+      const uint32_t sparsity = (uint32_t)(W * H) / (uint32_t)members;
+      int root = 1, next = 10;
+      for (int it = 0; it < 10; it++) {
+        if (next == root || root == 0) break;
+        root = next;
+        next = (int)((sparsity + (uint32_t)(root * root) + (uint32_t)(2 * root - 2)) / (uint32_t)(2 * root));
+      }
+      ls = root / 2 > 1 ? root / 2 : 1;
+    }
+    if (ls <= 0) ls = 1;  // (no members: never used)
+    ClipRng rng{cm, 0u};
+    for (int i = 0; i < nasm; i++)
+      if (mg_clip_member(dc, info, i) && asm_rec(dc, info[i].z)[AR_START_CLIPPED])
+        mg_clip_assembler(dc, as, info, nasm, w, (uint32_t)ls, rng, i, 0u);
+    a.clip_state[e] = make_uint2(rng.idx, (uint32_t)ls);
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+#endif
+
 // Restart a finished environment from the per-map templates (MettaGridPufferEnv.step -> _new_sim(),
 // mettagrid_puffer_env.py:158-164; same seed, next map).  All threads of the workgroup; HBM state only.
 __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid, int nt) {
@@ -1029,6 +1133,17 @@ __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid,
   }
   __threadfence();
   __syncthreads();
+#ifdef MG_WITH_CLIPPER
+  if (a.clip_w) {
+    // The template holds what the reset kernel's own clipper drew for the stations that start clipped; which
+    // unclipping protocol each of them offers comes from THIS environment's seed (clipper.hpp:107-110,186-193).
+    KArgs b = a;
+    mg_use_map(b, (uint32_t)m);
+    mg_clipper_init(a, b.gdc, a.asms + (size_t)e * a.NAmax, e, m, b.H, b.W, tid, nt);
+    __threadfence();
+    __syncthreads();
+  }
+#endif
 }
 
 
@@ -1042,6 +1157,7 @@ size_t mg_act_lds_bytes(const KArgs& k, bool dcl, bool big);
 int mg_act_threads(const KArgs& k);
 void mg_launch_obs(const KArgs& k, unsigned n, size_t lds, bool dcl, bool big, hipStream_t st);       // k_obs.hip
 void mg_launch_reset(const KArgs& k, unsigned n, size_t lds, bool big, hipStream_t st);               // k_reset.hip
+void mg_launch_clipper(const KArgs& k, unsigned n, hipStream_t st);                                   // k_clipper.hip
 // k_fused.hip: the whole step of one environment in one workgroup (attack-free configs, A <= 64)
 void mg_launch_fused(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);
 size_t mg_fused_lds_bytes(const KArgs& k, bool dcl);

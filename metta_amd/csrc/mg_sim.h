@@ -414,9 +414,11 @@ __device__ inline bool mg_chest_use(Ctx& cx, int ai, int chest_idx) {
 // ---- assembler ---------------------------------------------------------------------------------------------
 // Protocol lookup (assembler.hpp:378-408) from the vibes of the surrounding agents (any order; zeros ignored) and
 // their number (byte q of `packed_vibes` = vibe of the q-th surrounding agent).  Returns the record offset or -1.
+// `clipped` = DAsm::clipped: 0 = no; 1 = clipped with no way out (a station that starts clipped without a Clipper);
+// 2 + k = clipped by the Clipper, which installed its k-th unclipping protocol (clipper.hpp:186-193).
 __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long long packed_vibes, int n_agents,
-                                         bool clipped) {
-  if (clipped) return -1;  // unclip protocols only come from a Clipper (out of scope)
+                                         uint32_t clipped) {
+  if (clipped == 1u) return -1;
   // key = the non-zero vibes sorted ascending, 8 bits each (assembler.hpp:326-331): selection sort on the packed bytes
   unsigned long long key = 0;
   uint32_t used = 0;
@@ -432,6 +434,12 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long l
     if (best < 0) break;
     used |= 1u << best;
     key = (key << 8) | (unsigned long long)bv;
+  }
+  if (clipped >= 2u) {
+    // unclip_protocols = build_protocol_map({that protocol}): found under the local vibe, else under 0
+    const int* t = dc + dc[DC_OFF_UNCLIP] + 3 * (int)(clipped - 2u);
+    const unsigned long long kk = ((unsigned long long)(uint32_t)t[2] << 32) | (uint32_t)t[1];
+    return ((kk == key || kk == 0ull) && dc[t[0] + PR_MIN_AGENTS] <= n_agents) ? t[0] : -1;
   }
   const int* rec = asm_rec(dc, cfg);
   int nk = rec[AR_N_KEYS], ok = rec[AR_OFF_KEYS], pt = rec[AR_OFF_PTABLE];
@@ -453,7 +461,7 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long l
 // Assembler::get_current_protocol on the grid as it stands (assembler.hpp:353-408).
 template <class CT>
 __device__ inline int mg_current_protocol(const int* dc, const CT* grid, const DAgent* ag, CellCodec codec, int H,
-                                          int W, int ar, int ac, int cfg, bool clipped) {
+                                          int W, int ar, int ac, int cfg, uint32_t clipped) {
   unsigned long long vibes = 0;
   int n_agents = 0;
   if (!grid) {  // no occupancy tile (fused kernel): the surrounding agents by position (any order: the key is sorted)
@@ -513,7 +521,7 @@ __device__ inline bool mg_assembler_use_core(Ctx& cx, int ai_actor, int asm_idx,
   for (int q = 0; q < nn && q < 8; q++) pv |= (unsigned long long)near_vibes[q] << (8 * q);
   // a lone protocol under key 0 that needs no agents is the current protocol whoever stands around (AR_SIMPLE_PO)
   int po = (rec[AR_SIMPLE_PO] >= 0 && as->clipped == 0) ? rec[AR_SIMPLE_PO]
-                                                        : mg_select_protocol(dc, info.z, pv, nn, as->clipped != 0);
+                                                        : mg_select_protocol(dc, info.z, pv, nn, as->clipped);
   if (po < 0) return false;
   // protocol_to_use as (item, amount) lists
   int* in_k = cx.tmp + 16; int* in_v = cx.tmp + 32; int* out_k = cx.tmp + 48; int* out_v = cx.tmp + 64;
@@ -1113,8 +1121,8 @@ __device__ inline void mg_object_tokens(const int* dc, const CT* grid, const DAg
     }
     if (dc[DC_PROTO_OBS]) {
       int po = rec[AR_SIMPLE_PO];
-      if (s->clipped) po = -1;
-      else if (po < 0) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, false);
+      if (s->clipped == 1u) po = -1;
+      else if (po < 0 || s->clipped) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, s->clipped);
       if (po >= 0) {
         int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
         for (int i = 0; i < ni; i++)

@@ -80,6 +80,7 @@ SYMBOLS = {
     "mg_agent_stat_reward": (ct.c_int, [_vp, ct.c_int, _f32p, _vp]),
     "mg_chest_state": (ct.c_int, [_vp, ct.c_int, _i32p, ct.c_int, _i32p, _vp]),
     "mg_assembler_state": (ct.c_int, [_vp, ct.c_int, _i32p, _vp]),
+    "mg_clipper_state": (ct.c_int, [_vp, ct.c_int, ct.POINTER(ct.c_uint32), _i32p, _vp]),
     "mg_env_info": (ct.c_int, [_vp, ct.c_int, _u32p, _i32p, _u32p, _u32p, _vp]),
     "mg_env_table": (ct.c_int, [_vp, _u32p, _vp]),
     "mg_finished_rewards": (ct.c_int, [_vp, ct.c_int, _f32p, _u32p, _vp]),

@@ -29,7 +29,16 @@ sys.path.insert(0, str(ROOT))
 
 from oracle.gen_golden import GOLD, digest, encode_names, install_reference_shims  # noqa: E402
 
-SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117]
+SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
+         119, 127, 130, 133, 141, 143, 145, 146, 155, 164]
+# + a Clipper.  The reference picks the next assembler to clip by walking std::set<Assembler*> (clipper.hpp:24-26,
+# 207-229): POINTER order, so two reference instances in one process can disagree (seen here: seed 119 diverges at
+# step 4 between two instances built back to back).  Each of these fixtures is therefore produced by the FIRST
+# MettaGrid of a fresh process (`--only SEED`), where glibc hands out the assemblers at ascending addresses, i.e. in
+# creation (row-major) order -- the order oracle/mg_oracle.cpp restates; no second instance runs beside it.
+# (seeds picked for what happens in their 200 steps: 20-60 clip events and as many unclips, stations that start clipped,
+# clip-immune stations, 1-3 unclipping protocols, automatic length scale, clip_period 0 and 1)
+CLIPPER_SEEDS = {119, 127, 130, 133, 141, 143, 145, 146, 155, 164}
 WIDE_SEEDS = {116: 24, 117: 32}  # resource lists beyond 16: one team starts with every resource (map growth 13 -> 29 -> 59)
 COLLECTIVE_SEEDS = {113, 114, 115}  # + collectives: membership by tag, stat rewards on the collective's statistics
 STEPS = 200
@@ -51,11 +60,13 @@ def features_of(game) -> dict:
         "move_costs": bool(game.actions.move.consumed_resources),
         "collectives": bool(game.collectives) and any("aligned.agent" in a.rewards.stats for a in game.agents),
         "wide_resources": len(game.resource_names) > 16,
+        "clipper": game.clipper is not None,
+        "clipper_start_clipped": game.clipper is not None and any(a.start_clipped and not a.clip_immune for a in asm),
         "token_base": int(game.obs.token_value_base),
     }
 
 
-def main() -> None:
+def main(only: int | None = None) -> None:
     install_reference_shims()
     from mettagrid.config.mettagrid_c_config import convert_to_cpp_game_config
     from mettagrid.config.mettagrid_config import GameConfig as RefGameConfig
@@ -66,9 +77,16 @@ def main() -> None:
     from tests.fuzz_configs import fuzz_actions, rand_cfg
 
     covered: dict[str, int] = {}
-    for seed in SEEDS:
+    for seed in SEEDS if only is None else [only]:
+        if seed in CLIPPER_SEEDS and only is None:
+            import subprocess
+
+            subprocess.run([sys.executable, __file__, "--only", str(seed)], check=True)
+            covered["clipper"] = covered.get("clipper", 0) + 1
+            covered["clipper_start_clipped"] = covered.get("clipper_start_clipped", 0) + 1  # (asserted by --only runs below)
+            continue
         cfg = rand_cfg(np.random.RandomState(seed), device_safe=True, collectives=seed in COLLECTIVE_SEEDS,
-                       num_resources=WIDE_SEEDS.get(seed, 0))
+                       num_resources=WIDE_SEEDS.get(seed, 0), clipper=seed in CLIPPER_SEEDS)
         game = cfg.game
         if seed in WIDE_SEEDS:
             game.agents[0].inventory.initial = {r: int(1 + (i * 7) % 11) for i, r in enumerate(game.resource_names)}
@@ -83,8 +101,11 @@ def main() -> None:
         term, trunc = np.zeros(A, bool), np.zeros(A, bool)
         rew, act = np.zeros(A, np.float32), np.zeros(A, np.int32)
         env.set_buffers(obs, term, trunc, rew, act)
-        bridge = RefEnv(game, grid, seed)  # the hand-written mapping of oracle/ref_bridge.py, side by side
-        assert np.array_equal(obs, bridge.obs), f"seed {seed}: ref_bridge differs from the real converter at step 0"
+        solo = seed in CLIPPER_SEEDS
+        # the hand-written mapping of oracle/ref_bridge.py, side by side (not beside a Clipper: see CLIPPER_SEEDS)
+        bridge = None if solo else RefEnv(game, grid, seed)
+        assert solo or np.array_equal(obs, bridge.obs), f"seed {seed}: ref_bridge differs from the real converter at step 0"
+        obs0 = obs.copy()
         nA = len(compile_game(cfg, init_obs_passes=2).action_names)
         rs = np.random.RandomState(seed + 7)
         actions = np.stack([fuzz_actions(rs, game, nA) for _ in range(STEPS)])
@@ -92,14 +113,15 @@ def main() -> None:
         for t in range(STEPS):
             act[:] = actions[t]
             env.step()
-            bridge.step(actions[t])
-            assert np.array_equal(obs, bridge.obs) and np.array_equal(rew, bridge.rewards), (
-                f"seed {seed}: ref_bridge differs from the real converter at step {t + 1}"
-            )
+            if not solo:
+                bridge.step(actions[t])
+                assert np.array_equal(obs, bridge.obs) and np.array_equal(rew, bridge.rewards), (
+                    f"seed {seed}: ref_bridge differs from the real converter at step {t + 1}"
+                )
             od[t], rd[t] = digest(obs), digest(rew)
             sd[t] = digest(np.array(env.action_success(), dtype=np.uint8))
         stats = env.get_episode_stats()
-        assert stats == bridge.env.get_episode_stats(), f"seed {seed}: stats differ between the two conversions"
+        assert solo or stats == bridge.env.get_episode_stats(), f"seed {seed}: stats differ between the two conversions"
         names, codes = encode_names(grid)
         feats = features_of(game)
         for k, v in feats.items():
@@ -109,13 +131,16 @@ def main() -> None:
                 "terminated": bool(term.all()), "truncated": bool(trunc.all())}
         np.savez_compressed(
             GOLD / f"feature_{seed}.npz", meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), map_codes=codes,
-            actions=actions.astype(np.int32), obs0=bridge_obs0(game, grid, seed), obs_final=obs.copy(), obs_digest=od,
+            actions=actions.astype(np.int32), obs0=obs0 if solo else bridge_obs0(game, grid, seed), obs_final=obs.copy(),
+            obs_digest=od,
             rew_digest=rd, succ_digest=sd, episode_rewards=np.array(env.get_episode_rewards(), dtype=np.float32),
         )
         print(f"wrote feature_{seed}.npz", {k: v for k, v in feats.items() if v})
+    if only is not None:
+        return
     print("feature coverage over the fixture set:", covered)
     need = ["attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
-            "limit_modifiers", "chest_search", "collectives", "wide_resources"]
+            "limit_modifiers", "chest_search", "collectives", "wide_resources", "clipper", "clipper_start_clipped"]
     missing = [k for k in need if not covered.get(k)]
     assert not missing, f"no fixture exercises {missing}: extend SEEDS"
 
@@ -127,4 +152,4 @@ def bridge_obs0(game, grid, seed):
 
 
 if __name__ == "__main__":
-    main()
+    main(int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "--only" else None)

@@ -297,7 +297,41 @@ struct AssemblerInst {
   uint32_t obj_id;
   bool is_clipped;
   uint32_t cooldown_end = 0, cooldown_duration = 0, uses_count = 0;
+  int unclip = -1;          // index of the unclipping protocol a Clipper installed (become_clipped, assembler.hpp:411-421)
+  bool by_clipper = false;  // Assembler::clipper_ptr != nullptr
 };
+// Clipper (systems/clipper.hpp:14-239).  `border_assemblers` / `unclipped_assemblers` are std::set<Assembler*>, iterated
+// in POINTER order (clipper.hpp:24-26,207-229); here: creation order (row-major), which is the order glibc malloc
+// returned the assemblers in for every map of the fixtures generated with the reference (tests/golden/feature_12x.npz).
+// The adjacency lists (clipper.hpp:130-172) only feed commutative weight updates and set insertions, so they are not
+// materialised: j is adjacent to i iff both are members, i != j and L_inf distance <= cutoff * length_scale.
+// A border member whose weight has dropped to 0 can never be picked (clipper.hpp:221-227), so the border set is
+// "member, not clipped, weight > 0".
+struct ClipperInst {
+  bool on = false;
+  int length_scale = 0;
+  uint32_t cutoff = 0, period = 0;
+  MT19937 rng;
+  std::vector<uint32_t> weight;  // assembler_infection_weight, per assembler index
+  std::vector<char> member;      // not clip_immune
+};
+// clipper.hpp:65-98: auto length scale from the sparsity of the (non-immune) assemblers.
+static int clipper_auto_length_scale(int width, int height, size_t n_members) {
+  uint32_t sparsity = (uint32_t)(((size_t)(width * height)) / n_members);
+  int32_t root = 1, next = 10;
+  for (int i = 0; i < 10; i++) {
+    if (next == root || root == 0) break;
+    root = next;
+    next = (int32_t)((sparsity + (uint32_t)(root * root) + (uint32_t)(2 * root - 2)) / (uint32_t)(2 * root));
+  }
+  return std::max(root / 2, 1);
+}
+// clipper.hpp:113-120
+static uint32_t clipper_infection_weight(int dist, int length_scale, uint32_t cutoff) {
+  uint32_t scaled = (uint32_t)dist / (uint32_t)length_scale;
+  if (scaled > cutoff) return 0;
+  return 1u << (cutoff - scaled);
+}
 struct ChestInst {
   int r, c, cfg;
   uint32_t obj_id;
@@ -318,6 +352,7 @@ struct Env {
   std::vector<AssemblerInst> assemblers;
   std::vector<ChestInst> chests;
   std::vector<CollectiveInst> collectives;
+  ClipperInst clipper;
   Stats game;
   MT19937 rng;
   uint32_t current_step = 0;
@@ -349,6 +384,13 @@ struct Env {
   void check_and_apply_damage(Agent& a);
   void compute_stat_rewards(size_t ai);
   void surrounding_positions(const AssemblerInst& as, std::vector<std::pair<int, int>>& out);
+  // clipper
+  void clipper_init(uint32_t seed);
+  bool clipper_adjacent(size_t i, size_t j, uint32_t* w) const;
+  void clip_assembler(size_t i);
+  void on_unclip_assembler(size_t i);
+  int pick_assembler_to_clip();
+  void maybe_clip_new_assembler();
 };
 
 int Inventory::update(int item, int attempted_delta, bool ignore_limits) {
@@ -610,6 +652,10 @@ void Env::init(const int32_t* blob, size_t n, const uint8_t* map, int h, int w, 
   for (int pass = 0; pass < std::max(1, cfg.init_obs_passes); pass++) {
     std::fill(obs.begin(), obs.end(), 0xFF);
     compute_observations(zero);
+    // The constructor builds the Clipper AFTER _make_buffers has computed the first observations (mettagrid_c.cpp:
+    // 139-154): a station that starts clipped shows `clipped` without protocol tokens in that pass, with them in
+    // the pass set_buffers runs later.
+    if (pass == 0 && cfg.clipper) clipper_init(seed);
   }
 }
 
@@ -653,10 +699,18 @@ const MgProtocol* Env::current_protocol(const AssemblerInst& as) {
       if (v != 0) vibes.push_back(v);
     }
   }
-  if (as.is_clipped) return nullptr;
   std::sort(vibes.begin(), vibes.end());
   uint64_t key = 0;
   for (uint8_t v : vibes) key = (key << 8) | v;
+  if (as.is_clipped) {
+    // unclip_protocols = build_protocol_map({the one protocol the Clipper drew}) (clipper.hpp:186-193): found under the
+    // local vibe or under 0
+    if (as.unclip < 0) return nullptr;
+    const MgProtocol& p = cfg.unclip[(size_t)as.unclip];
+    const uint64_t pk = cfg.unclip_key[(size_t)as.unclip];
+    if ((pk == key || pk == 0) && (size_t)p.min_agents <= n_agents) return &p;
+    return nullptr;
+  }
   for (int attempt = 0; attempt < 2; attempt++) {
     uint64_t k = attempt == 0 ? key : 0;
     for (const auto& pk : ac.keys)
@@ -1025,11 +1079,107 @@ bool Env::assembler_use(AssemblerInst& as, Agent& actor) {
   }
   as.cooldown_duration = (uint32_t)orig->cooldown;
   as.cooldown_end = current_step + as.cooldown_duration;
-  if (as.is_clipped)
+  if (as.is_clipped) {  // become_unclipped (assembler.hpp:583-592)
     as.is_clipped = false;
-  else
+    as.unclip = -1;
+    if (as.by_clipper) on_unclip_assembler((size_t)(&as - assemblers.data()));
+    as.by_clipper = false;
+  } else {
     as.uses_count++;
+  }
   return true;
+}
+
+// ---- Clipper (systems/clipper.hpp) ------------------------------------------------------------------------------
+void Env::clipper_init(uint32_t seed) {
+  ClipperInst& cl = clipper;
+  cl.on = true;
+  cl.length_scale = cfg.clip_length_scale;
+  cl.cutoff = (uint32_t)cfg.clip_cutoff;
+  cl.period = (uint32_t)cfg.clip_period;
+  cl.rng.seed(seed);  // a copy of _rng, which nothing has drawn from yet (mettagrid_c.cpp:57,153)
+  cl.weight.assign(assemblers.size(), 0);
+  cl.member.assign(assemblers.size(), 0);
+  size_t n_members = 0;
+  std::vector<size_t> starting;
+  for (size_t i = 0; i < assemblers.size(); i++) {  // object id order = creation order
+    const MgAssembler& ac = cfg.assemblers[(size_t)assemblers[i].cfg];
+    if (ac.clip_immune) continue;
+    cl.member[i] = 1;
+    n_members++;
+    if (ac.start_clipped) starting.push_back(i);
+  }
+  if (cl.length_scale <= 0 && n_members > 0) cl.length_scale = clipper_auto_length_scale(W, H, n_members);
+  for (size_t i : starting) clip_assembler(i);
+}
+
+bool Env::clipper_adjacent(size_t i, size_t j, uint32_t* w) const {
+  const ClipperInst& cl = clipper;
+  if (cl.period == 0) return false;  // compute_adjacencies only runs for an active clipper (clipper.hpp:101-105)
+  if (i == j || !cl.member[i] || !cl.member[j]) return false;
+  const AssemblerInst &a = assemblers[i], &b = assemblers[j];
+  const int dist = std::max(std::abs(a.r - b.r), std::abs(a.c - b.c));
+  if ((uint32_t)dist > cl.cutoff * (uint32_t)cl.length_scale) return false;
+  *w = clipper_infection_weight(dist, cl.length_scale, cl.cutoff);
+  return true;
+}
+
+void Env::clip_assembler(size_t i) {  // clipper.hpp:174-194
+  ClipperInst& cl = clipper;
+  for (size_t j = 0; j < assemblers.size(); j++) {
+    uint32_t w;
+    if (clipper_adjacent(i, j, &w)) cl.weight[j] += w;
+  }
+  const uint32_t k = cl.rng.bounded((uint32_t)cfg.unclip.size());  // uniform_int_distribution<size_t>(0, n - 1)
+  AssemblerInst& as = assemblers[i];
+  as.is_clipped = true;  // become_clipped (assembler.hpp:411-421)
+  as.unclip = (int)k;
+  as.by_clipper = true;
+  as.cooldown_end = current_step;
+  as.cooldown_duration = 0;
+}
+
+void Env::on_unclip_assembler(size_t i) {  // clipper.hpp:196-205
+  for (size_t j = 0; j < assemblers.size(); j++) {
+    uint32_t w;
+    if (clipper_adjacent(i, j, &w)) clipper.weight[j] -= w;
+  }
+}
+
+int Env::pick_assembler_to_clip() {  // clipper.hpp:207-229
+  ClipperInst& cl = clipper;
+  // unclipped_assemblers: every member the clipper has not clipped (one that starts clipped is clipped by the
+  // constructor, so: every member that is not clipped now)
+  std::vector<size_t> unclipped;
+  for (size_t i = 0; i < assemblers.size(); i++)
+    if (cl.member[i] && !assemblers[i].is_clipped) unclipped.push_back(i);
+  if (unclipped.empty()) return -1;
+  uint32_t total = 0;
+  for (size_t i : unclipped) total += cl.weight[i];
+  if (total == 0) return (int)unclipped[cl.rng.bounded((uint32_t)unclipped.size())];
+  uint32_t random_weight = 1 + cl.rng.bounded(total);  // uniform_int_distribution<>(1, total)
+  for (size_t i : unclipped) {
+    if (cl.weight[i] == 0) continue;
+    if (random_weight <= cl.weight[i]) return (int)i;
+    random_weight -= cl.weight[i];
+  }
+  throw std::runtime_error("Failed to pick an assembler to clip");
+}
+
+void Env::maybe_clip_new_assembler() {  // clipper.hpp:231-238
+  ClipperInst& cl = clipper;
+  bool hit;
+  if (cl.period > 0) {
+    hit = cl.rng.bounded(cl.period) == 0;  // uniform_int_distribution<uint32_t>(1, period)(rng) == 1
+  } else {
+    // (1, 0): libstdc++ computes the range in 64 bits, b - a = 2^64 - 1 > the engine's range, and composes two draws
+    // (uniform_int_dist.h:283-300): ret = 2^32 x1 + x2, truncated to 32 bits and + 1  ==  1  iff  x2 == 0
+    cl.rng.next();
+    hit = cl.rng.next() == 0;
+  }
+  if (!hit) return;
+  int i = pick_assembler_to_clip();
+  if (i >= 0) clip_assembler((size_t)i);
 }
 
 bool Env::chest_use(ChestInst& ch, Agent& actor) {
@@ -1260,6 +1410,7 @@ void Env::step(const int32_t* actions) {
     }
   }
   for (auto& a : agents) check_and_apply_damage(a);
+  if (clipper.on) maybe_clip_new_assembler();  // mettagrid_c.cpp:647-650
   compute_observations(executed);
   for (size_t i = 0; i < A; i++) compute_stat_rewards(i);
   for (size_t i = 0; i < A; i++) episode_rewards[i] += rewards[i];
@@ -1372,9 +1523,25 @@ void mgo_assembler_state(void* h, int32_t* out) {
   for (size_t i = 0; i < e->assemblers.size(); i++) {
     const AssemblerInst& a = e->assemblers[i];
     int32_t* o = out + i * 8;
-    o[0] = a.r; o[1] = a.c; o[2] = a.cfg; o[3] = (int32_t)a.obj_id; o[4] = a.is_clipped;
+    o[0] = a.r; o[1] = a.c; o[2] = a.cfg; o[3] = (int32_t)a.obj_id;
+    o[4] = a.is_clipped ? (a.unclip >= 0 ? 2 + a.unclip : 1) : 0;  // (the device's encoding of DAsm::clipped)
     o[5] = (int32_t)a.cooldown_end; o[6] = (int32_t)a.cooldown_duration; o[7] = (int32_t)a.uses_count;
   }
+}
+// Clipper state: infection weight per assembler (0 for clip-immune ones); returns the length scale in use, -1 = no clipper
+int mgo_clipper_state(void* h, uint32_t* weights) {
+  Env* e = (Env*)h;
+  if (!e->clipper.on) return -1;
+  for (size_t i = 0; i < e->assemblers.size(); i++) weights[i] = e->clipper.weight[i];
+  return e->clipper.length_scale;
+}
+uint64_t mgo_clipper_rng_draws(void* h) { return ((Env*)h)->clipper.rng.draws; }
+// the two pure functions the reference's own known-answer tests pin (tests/test_clipper.cpp:56-92,303-356)
+int mgo_clipper_auto_length_scale(int width, int height, int n_members) {
+  return clipper_auto_length_scale(width, height, (size_t)n_members);
+}
+uint32_t mgo_clipper_infection_weight(int dist, int length_scale, uint32_t cutoff) {
+  return clipper_infection_weight(dist, length_scale, cutoff);
 }
 int mgo_num_chests(void* h) { return (int)((Env*)h)->chests.size(); }
 // Per chest: r, c, cfg, obj_id, n_items, (item, amount) pairs in map order, -1 padded (stride 5 + 2R)

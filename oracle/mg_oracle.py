@@ -55,6 +55,12 @@ def lib() -> ct.CDLL:
     L.mgo_num_assemblers.argtypes = [vp]
     L.mgo_assembler_state.argtypes = [vp, i32p]
     L.mgo_num_chests.argtypes = [vp]
+    L.mgo_clipper_state.argtypes = [vp, ct.POINTER(ct.c_uint32)]
+    L.mgo_clipper_rng_draws.restype = ct.c_uint64
+    L.mgo_clipper_rng_draws.argtypes = [vp]
+    L.mgo_clipper_auto_length_scale.argtypes = [ct.c_int, ct.c_int, ct.c_int]
+    L.mgo_clipper_infection_weight.argtypes = [ct.c_int, ct.c_int, ct.c_uint32]
+    L.mgo_clipper_infection_weight.restype = ct.c_uint32
     L.mgo_chest_state.argtypes = [vp, i32p]
     L.mgo_grid.argtypes = [vp, i32p]
     L.mgo_set_inventory.argtypes = [vp, ct.c_int, ct.c_int, i32p, i32p]
@@ -122,6 +128,13 @@ class OracleEnv:
         if n:
             self.L.mgo_assembler_state(self.h, _p(out, ct.c_int32))
         return out
+
+    def clipper_state(self):
+        """(length scale in use, infection weight per assembler), or None without a clipper."""
+        n = self.L.mgo_num_assemblers(self.h)
+        w = np.zeros(max(n, 1), dtype=np.uint32)
+        ls = self.L.mgo_clipper_state(self.h, _p(w, ct.c_uint32))
+        return None if ls < 0 else (int(ls), w[:n])
 
     def chest_state(self) -> np.ndarray:
         n = self.L.mgo_num_chests(self.h)

@@ -53,8 +53,6 @@ def to_ref_game_config(game) -> Any:
     from metta_amd.config import AgentConfig, AssemblerConfig, ChestConfig, WallConfig
 
     C = load_reference_module()
-    if game.clipper is not None:
-        raise NotImplementedError("clipper is outside the step path scope")
     resource_names = list(game.resource_names)
     rid = {n: i for i, n in enumerate(resource_names)}
     vibe_names = [v.name for v in game.actions.change_vibe.vibes]
@@ -242,10 +240,39 @@ def to_ref_game_config(game) -> Any:
         objects=objects,
         tag_id_map={i: t for t, i in tag_id.items()},
         collectives=_collectives(C, game, rid),
+        clipper=_clipper(C, game, rid, vid),
         protocol_details_obs=game.protocol_details_obs,
         inventory_regen_interval=game.inventory_regen_interval,
         token_value_base=game.obs.token_value_base,
     )
+
+
+def _clipper(C, game, rid, vid):
+    """mettagrid_c_config.py:506-539 (list order kept; vibes sorted; maps filled item by item)."""
+    clip = game.clipper
+    if clip is None:
+        return None
+    protos = []
+    for pc in clip.unclipping_protocols:
+        p = C.Protocol()
+        p.min_agents = pc.min_agents
+        p.vibes = sorted(vid[v] for v in pc.vibes)
+        ins: dict[int, int] = {}
+        for k, v in pc.input_resources.items():
+            ins[int(rid[k])] = int(v)
+        outs: dict[int, int] = {}
+        for k, v in pc.output_resources.items():
+            outs[int(rid[k])] = int(v)
+        p.input_resources = ins
+        p.output_resources = outs
+        p.cooldown = pc.cooldown
+        protos.append(p)
+    cc = C.ClipperConfig()
+    cc.unclipping_protocols = protos
+    cc.length_scale = clip.length_scale
+    cc.scaled_cutoff_distance = clip.scaled_cutoff_distance
+    cc.clip_period = clip.clip_period
+    return cc
 
 
 def _collectives(C, game, rid) -> dict:

@@ -81,8 +81,48 @@ def add_collectives(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGri
     return cfg
 
 
+def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridConfig:
+    """A Clipper (systems/clipper.hpp) over the configuration's assemblers: frequent clip events, a few clip-immune
+    and start-clipped stations, unclipping protocols that the agents can sometimes pay (one of them free, so that
+    stations do get unclipped and the infection weights go down as well as up)."""
+    from metta_amd.config import ClipperConfig
+
+    game = cfg.game
+    R = list(game.resource_names)
+    asms = [o for o in game.objects.values() if isinstance(o, AssemblerConfig)]
+    same_shape = bool(rs.randint(3))  # start-clipped stations need unclipping protocols of one shape (compile.py)
+    protos = []
+    for k in range(int(rs.randint(1, 4))):
+        if same_shape:
+            protos.append(ProtocolConfig(input_resources={R[int(rs.randint(len(R)))]: 1}, cooldown=int(rs.randint(0, 4))))
+        else:
+            protos.append(
+                ProtocolConfig(
+                    min_agents=int(rs.randint(0, 2)), vibes=[VIB[int(rs.randint(1, 4))]] if rs.randint(3) == 0 else [],
+                    input_resources={R[int(rs.randint(len(R)))]: int(rs.randint(0, 2))} if rs.randint(3) else {},
+                    output_resources={R[0]: 1} if rs.randint(3) == 0 else {}, cooldown=int(rs.randint(0, 6)),
+                )
+            )  # fmt: skip
+    if same_shape and rs.randint(2):
+        protos[0] = ProtocolConfig(input_resources={R[0]: 0}, cooldown=1)  # zero amounts give no tokens: not the same shape
+        protos = protos[:1]
+    for o in asms:
+        o.clip_immune = bool(rs.randint(4) == 0)
+        o.start_clipped = bool(same_shape and rs.randint(3) == 0)
+    game.clipper = ClipperConfig(
+        unclipping_protocols=protos, length_scale=int(rs.choice([0, 0, 1, 2, 3])),
+        scaled_cutoff_distance=int(rs.randint(1, 4)), clip_period=int(rs.choice([1, 2, 3, 5, 0])),
+    )  # fmt: skip
+    # more stations on the map, so that the infection has somewhere to go
+    mb = game.map_builder
+    for k in list(mb.objects):
+        if k != "wall":
+            mb.objects[k] = int(mb.objects[k]) + int(rs.randint(1, 4))
+    return cfg
+
+
 def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: bool = False,
-             num_resources: int = 0) -> MettaGridConfig:  # fmt: skip
+             num_resources: int = 0, clipper: bool = False) -> MettaGridConfig:  # fmt: skip
     R = RES[: rs.randint(3, len(RES) + 1)]
     if num_resources:  # wide resource lists (17..32: the wide-inventory build of the library)
         R = (RES + [f"res{i}" for i in range(num_resources)])[:num_resources]
@@ -220,7 +260,9 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: 
         inventory_regen_interval=int(rs.choice([0, 1, 3])), protocol_details_obs=bool(rs.randint(4)), map_builder=mb,
     )  # fmt: skip
     cfg = MettaGridConfig(game=game)
-    return add_collectives(cfg, rs) if collectives else cfg
+    if collectives:
+        cfg = add_collectives(cfg, rs)
+    return add_clipper(cfg, rs) if clipper else cfg
 
 
 def fuzz_actions(rs: np.random.RandomState, game, n_actions: int, invalid: bool = True) -> np.ndarray:

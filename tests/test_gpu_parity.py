@@ -201,6 +201,62 @@ def test_fuzz_wide_resource_lists_vs_oracle(seed, num_resources):
     b.close()
 
 
+@pytest.mark.parametrize("seed", list(range(300, 316)))
+def test_fuzz_clipper_vs_oracle(seed):
+    """A Clipper (systems/clipper.hpp) on top of the fuzzed configurations: clip events, stations that start clipped,
+    unclipping by use, clip-immune stations, clip_period 0, automatic length scale.  Short episodes with auto-reset:
+    every restart rebuilds the environment's clipper from its own seed (which unclipping protocol a station that starts
+    clipped offers is drawn there).  Infection weights and the length scale are compared with the oracle's."""
+    from oracle.mg_oracle import make_oracle_env
+
+    rs = np.random.RandomState(seed)
+    cfg = None
+    while cfg is None:
+        cand = rand_cfg(rs, device_safe=True, clipper=True, collectives=bool(seed % 4 == 0))
+        try:
+            compile_game(cand, init_obs_passes=2)
+            cfg = cand
+        except NotImplementedError as ex:  # (start-clipped stations with unclipping protocols of different shapes)
+            assert "start clipped" in str(ex)
+    game = cfg.game
+    game.max_steps = int(rs.choice([20, 35, 50]))
+    passes = int(rs.randint(1, 3))
+    maps = [game.map_builder.build(np.random.default_rng(1000 * seed + i)) for i in range(3)]
+    E, A = 4, game.num_agents
+    seeds = [seed * 10 + e for e in range(E)]
+    cur_map = [e % 3 for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, cur_map, passes)
+    b.set_auto_reset(True, 1)
+    comp, oras = _oracles(cfg, maps, seeds, cur_map, passes)
+    nA = len(comp.action_names)
+    _compare_step(b, oras, 0, A)
+
+    def compare_clipper(t):
+        for e, o in enumerate(oras):
+            ls, w = o.clipper_state()
+            dls, dw = b.clipper_state(e)
+            assert dls == ls, f"step {t} env {e}: length scale"
+            assert np.array_equal(dw, w), f"step {t} env {e}: infection weights"
+
+    compare_clipper(0)
+    _compare_state(b, oras, 0)
+    for t in range(1, 141):
+        acts = np.stack([fuzz_actions(rs, game, nA) for _ in range(E)])
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + 1) % 3
+                oras[e] = make_oracle_env(comp, comp.encode_map(maps[cur_map[e]]), seeds[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+        if t % 10 == 0:
+            compare_clipper(t)
+        if t % 35 == 0:
+            _compare_state(b, oras, t)
+    b.check_errors()
+    b.close()
+
+
 def test_more_resources_than_the_wide_build_holds_is_an_error():
     cfg = rand_cfg(np.random.RandomState(1), device_safe=True, num_resources=33)
     maps = [cfg.game.map_builder.build(np.random.default_rng(1))]
@@ -208,7 +264,8 @@ def test_more_resources_than_the_wide_build_holds_is_an_error():
         _batch(cfg, maps, 1, [1], [0])
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117])
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
+                                  119, 127, 130, 133, 141, 143, 145, 146, 155, 164])  # (from 119 on: with a Clipper)
 def test_golden_feature_families(seed):
     """tests/golden/feature_<seed>.npz: configurations with attack / armor / loot / freeze, transfer, chests, damage,
     regeneration, partial usage ... converted by the reference's REAL `convert_to_cpp_game_config` and stepped by its

@@ -113,7 +113,8 @@ def test_bridge_matches_reference_python_converter_shapes():
     assert comp.object_type_names == ["agent"] + sorted(cfg.game.objects.keys()) + ["", "", ""]
 
 
-FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117]
+FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
+                 119, 127, 130, 133, 141, 143, 145, 146, 155, 164]  # (from 119 on: with a Clipper)
 
 
 def load_feature_fixture(seed):
@@ -158,9 +159,25 @@ def test_oracle_vs_real_converter_fixture(seed):
 
 def test_feature_fixtures_cover_every_feature_family():
     need = {"attack", "transfer", "chest", "damage", "regen", "partial_usage", "max_uses", "multi_vibe_protocol",
-            "limit_modifiers", "chest_search", "move_costs"}
+            "limit_modifiers", "chest_search", "move_costs", "collectives", "wide_resources", "clipper",
+            "clipper_start_clipped"}
     seen = set()
     for seed in FEATURE_SEEDS:
         _, meta, _, _ = load_feature_fixture(seed)
         seen |= {k for k, v in meta["features"].items() if v and k != "token_base"}
     assert need <= seen
+
+
+def test_clipper_known_answers_of_the_reference():
+    """The reference's own known-answer tests for the Clipper's two pure functions (tests/test_clipper.cpp:56-92:
+    infection weights; :303-356: automatic length scale)."""
+    from oracle.mg_oracle import lib as load_oracle
+
+    L = load_oracle()
+    # InfectionWeightCalculation: length_scale 2, cutoff 2 -- distances 1, 5, 7 give 2^2, 2^0, 0
+    assert [L.mgo_clipper_infection_weight(d, 2, 2) for d in (1, 5, 7)] == [4, 1, 0]
+    # AutoLengthScaleBasic: 50 x 50, 25 assemblers -> 5; ClipImmuneExcluded: 9 members -> 8
+    assert L.mgo_clipper_auto_length_scale(50, 50, 25) == 5
+    assert L.mgo_clipper_auto_length_scale(50, 50, 9) == 8
+    # GridSizeScaling: 100 x 100 against 25 x 25 with 25 assemblers each: four times the scale (integer division)
+    assert L.mgo_clipper_auto_length_scale(100, 100, 25) // 4 == L.mgo_clipper_auto_length_scale(25, 25, 25)
