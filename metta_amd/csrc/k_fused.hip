@@ -19,6 +19,7 @@
 // the prefix of the config stream that the use / token code walks with dependent reads is staged.
 // Against the three-kernel path the agent records are read and written once instead of three times, and the hand-over
 // buffers (mode / pending uses / executed action) never leave LDS.
+#define MG_NO_CLIPPER  // (configurations with a Clipper take the general kernels)
 #include "mg_kernels.h"
 
 // Built twice: as is, and through k_fused_nomod.hip with MG_NO_MODIFIERS (configurations without inventory-limit

@@ -1,4 +1,5 @@
 // k_uses.hip -- see mg_kernels.h / DESIGN.md section 4
+#define MG_NO_CLIPPER  // (configurations with a Clipper take the general kernels)
 #include "mg_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------

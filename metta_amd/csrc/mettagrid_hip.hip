@@ -15,6 +15,7 @@
 //                                            damage / regen, any A); BIG = grids and records in HBM
 //   k_reset.hip        mg_reset_kernel       MettaGrid construction + step-0 observations; builds the episode-start templates
 //   k_mapgen.hip       mg_generate_maps_kernel  device map pool (border + uniform shuffle per room) and its refresh
+//   k_clipper.hip      mg_clipper_kernel        the Clipper's turn between the action and the observation kernel
 //   advantage.hip      mg_advantage_kernel   V-trace / GAE row scan (mg_compute_advantage)
 //
 // There is no CPU fallback: every entry point runs HIP kernels or fails.

@@ -418,7 +418,11 @@ __device__ inline bool mg_chest_use(Ctx& cx, int ai, int chest_idx) {
 // 2 + k = clipped by the Clipper, which installed its k-th unclipping protocol (clipper.hpp:186-193).
 __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long long packed_vibes, int n_agents,
                                          uint32_t clipped) {
+#ifdef MG_NO_CLIPPER  // (kernels that never run a configuration with a Clipper: k_fused, k_act_fast, k_uses)
+  if (clipped) return -1;
+#else
   if (clipped == 1u) return -1;
+#endif
   // key = the non-zero vibes sorted ascending, 8 bits each (assembler.hpp:326-331): selection sort on the packed bytes
   unsigned long long key = 0;
   uint32_t used = 0;
@@ -435,12 +439,14 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long l
     used |= 1u << best;
     key = (key << 8) | (unsigned long long)bv;
   }
+#ifndef MG_NO_CLIPPER
   if (clipped >= 2u) {
     // unclip_protocols = build_protocol_map({that protocol}): found under the local vibe, else under 0
     const int* t = dc + dc[DC_OFF_UNCLIP] + 3 * (int)(clipped - 2u);
     const unsigned long long kk = ((unsigned long long)(uint32_t)t[2] << 32) | (uint32_t)t[1];
     return ((kk == key || kk == 0ull) && dc[t[0] + PR_MIN_AGENTS] <= n_agents) ? t[0] : -1;
   }
+#endif
   const int* rec = asm_rec(dc, cfg);
   int nk = rec[AR_N_KEYS], ok = rec[AR_OFF_KEYS], pt = rec[AR_OFF_PTABLE];
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -1121,8 +1127,13 @@ __device__ inline void mg_object_tokens(const int* dc, const CT* grid, const DAg
     }
     if (dc[DC_PROTO_OBS]) {
       int po = rec[AR_SIMPLE_PO];
+#ifdef MG_NO_CLIPPER
+      if (s->clipped) po = -1;
+      else if (po < 0) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, 0u);
+#else
       if (s->clipped == 1u) po = -1;
       else if (po < 0 || s->clipped) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, s->clipped);
+#endif
       if (po >= 0) {
         int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
         for (int i = 0; i < ni; i++)
