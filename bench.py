@@ -5,17 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch: `mg_step` over 4096 arena environments x 24 agents per GPU
-(BASELINE.json configs[1]; 98 304 agent-steps per GPU per step) with seeded uniform-random actions that are already
-resident in HBM when the timed region starts (a pre-generated [64, N] int32 action table; each step reads one row in
-place through `mg_step_actions`).  Auto-reset is on, so episode turnover is inside the timed region.
+One "step" = one pass of the hot path over one batch: every one of the 4096 arena environments x 24 agents of a GPU
+(BASELINE.json configs[1]; 98 304 agent-steps per GPU per step) advances one tick, with seeded uniform-random actions
+that are already resident in HBM when the timed region starts (a pre-generated [64, N] int32 action table; each step
+reads one row in place through `mg_step_actions`).  Auto-reset is on, so episode turnover is inside the timed region.
+
+The environments are stepped as `--groups` G independent groups (default 4: environments [g E/G, (g+1) E/G) of the rank),
+each group a handle of its own on its own HIP stream: a group's step k+1 is ordered after its own step k and nothing
+else.  This is the reference's double buffering (`async_factor`, RL/training/training_environment.py:45-46,151-170;
+pufferlib `Multiprocessing` with batch_size < num_envs, vector.py:415-503; here `metta_amd.vecenv.AsyncDeviceVecEnv`):
+the environments of one group are stepped while the policy works on another's observations.  One kernel alone ends
+with a tail in which most CUs wait for its slowest workgroups; with G launches in flight the other groups' workgroups
+fill it.  Environment ids, seeds, maps and actions are those of the single-handle case; `single_stream` in the output
+is the same workload through ONE handle on one stream, measured right after the timed region (`--groups 1` makes that
+the headline).
 Environments shard across ranks as independent instances (no data-path collective: "scaling": "weak"); the only
 collective is the RCCL all-reduce of the finished-episode summary vector every 128 steps.
 
 Prints ONE JSON line on rank 0.  `roofline`: algorithmic bytes per launch (1035 B per agent-step, SURVEY §8d:
-610 B boundary + ~425 B state; one launch = one step = the fused kernel mg_step_fused*_kernel) / mean kernel duration
-measured with HIP events on the launch stream over the timed steps (every 8th step is bracketed: the event pair is not
-free); `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
+610 B boundary + ~425 B state; one launch = one step of one group = the fused kernel mg_step_fused*_kernel over E/G
+environments) / mean kernel duration measured with HIP events on the launch's own stream over the timed steps (every
+8th step of every group is bracketed: the event pair is not free).  G such launches are in flight at any time (one per
+stream, back to back), so the rate the GPU sustains is `achieved` = `concurrency` x bytes per launch / mean launch
+duration; `per_launch_achieved` is the one-launch figure the formula of SURVEY §8d gives without the factor.
+`traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
 `cpu_baseline`: the reference's own compiled core (oracle/_ref, kind "reference") or the oracle port, stepped on
 the host cores over a bounded sample of the same workload, rank 0 / N=1 only.
 """
@@ -132,7 +145,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--groups", type=int, default=4, help="independent environment groups, one HIP stream each (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-handle comparison run (profiling passes: one launch shape only)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL summary all-reduce even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -166,36 +181,65 @@ def main() -> None:
         dist.init_process_group(backend="nccl", device_id=dev)
 
     E, A = args.envs, AGENTS
+    G = args.groups if args.groups >= 1 and E % max(args.groups, 1) == 0 else 1
+    n = E // G
     cfg = make_arena(A)
     pool = _load_pool()
     seeds, map_ids = bench_shard(rank, E, len(pool))  # env g: seed g (pufferlib vector.py:90), map g mod pool
-    batch = MettaGridBatch(cfg, E, pool, device=local_rank, init_obs_passes=2, seeds=seeds, map_ids=map_ids)
-    batch.set_auto_reset(True, 1)
     # desynchronise episode phases like the reference's EarlyResetHandler (early_reset_handler.py:6-20)
-    batch.set_early_reset(np.random.RandomState(rank).randint(1, cfg.game.max_steps + 1, size=E).astype(np.uint32))
-
+    early = np.random.RandomState(rank).randint(1, cfg.game.max_steps + 1, size=E).astype(np.uint32)
     N = E * A
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     table = torch.randint(0, 5, (64, N), generator=g, device=dev, dtype=torch.int32)
-    summary = torch.zeros(3 + len(batch.compiled.game_slot_names), dtype=torch.float64, device=dev)
+
+    def make_batches(groups: int):
+        m = E // groups
+        out = []
+        for q in range(groups):
+            b = MettaGridBatch(cfg, m, pool, device=local_rank, init_obs_passes=2, seeds=seeds[q * m : (q + 1) * m],
+                               map_ids=map_ids[q * m : (q + 1) * m])  # fmt: skip
+            b.set_auto_reset(True, 1)
+            b.set_early_reset(early[q * m : (q + 1) * m])
+            out.append(b)
+        return out
+
+    batches = make_batches(G)
+    tables = [table[:, q * n * A : (q + 1) * n * A].contiguous() for q in range(G)] if G > 1 else [table]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(G)] if G > 1 else [torch.cuda.current_stream(dev)]
+    summary = torch.zeros(3 + len(batches[0].compiled.game_slot_names), dtype=torch.float64, device=dev)
 
     def sync_all():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    acc = batch.summary_tensor()  # f64 accumulators in HBM, added to by the step kernels when an episode ends
+    accs = [b.summary_tensor() for b in batches]  # f64 accumulators in HBM, added to by the step kernels when an episode ends
 
     def reduce_summary():
         # the only collective of the path: < 1 KB, on the stream, no host round trip
-        s = acc.clone()
-        acc.zero_()
+        cur = torch.cuda.current_stream(dev)
+        for st in streams:
+            cur.wait_stream(st)
+        s = accs[0].clone()
+        accs[0].zero_()
+        for acc in accs[1:]:
+            s += acc
+            acc.zero_()
+        for st in streams:
+            st.wait_stream(cur)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         summary.add_(s)
 
-    def run(k: int, base: int):
+    def run(k: int, base: int, bs=None, tbs=None, sts=None):
+        bs, tbs, sts = bs or batches, tbs or tables, sts or streams
+        # (tensors validated here once; the loop hands the library raw pointers and stream handles)
+        assert all(tb.dtype == torch.int32 and tb.is_contiguous() and tb.shape[1] == b.actions.numel() for b, tb in zip(bs, tbs))
+        ptrs = [[tb[r].data_ptr() for r in range(64)] for tb in tbs]
+        calls = [(b.step_raw, ptrs[q], sts[q].cuda_stream) for q, b in enumerate(bs)]
         for t in range(k):
-            batch.step(table[(base + t) % 64])
+            row = (base + t) % 64
+            for step_raw, p, sh in calls:
+                step_raw(p[row], sh)
             if use_dist and (base + t) % 128 == 127:
                 reduce_summary()
 
@@ -204,25 +248,55 @@ def main() -> None:
         reduce_summary()  # communicator set-up and first-use costs stay out of the timed region
     sync_all()
     # HIP events around every 8th step of the timed region: an event pair per step costs ~7 % of the step it times
-    batch.set_profiling(True, stride=PROFILE_STRIDE)
+    for b in batches:
+        b.set_profiling(True, stride=PROFILE_STRIDE)
     t0 = time.perf_counter()
     run(args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
-    kernel_ms = batch.profile_read(4096)
-    batch.set_profiling(False)
-    step_path = batch.step_path()
+    kernel_ms = np.concatenate([b.profile_read(4096) for b in batches])
+    for b in batches:
+        b.set_profiling(False)
+    step_path = batches[0].step_path()
     fused = "fused" in step_path
     obs_ms = np.zeros(0, np.float32)
-    if not fused:
+    if not fused and G == 1:
         # after the timed region: a short pass with events around the observation kernel alone (SURVEY 8d metric 2)
-        batch.set_profiling(2)
+        batches[0].set_profiling(2)
         n_obs = min(args.steps, 100)
         run(n_obs, args.warmup + args.steps)
         sync_all()
-        obs_ms = batch.profile_read(4096)
-        batch.set_profiling(False)
-    batch.check_errors()  # an environment that left reference parity would void the measurement
+        obs_ms = batches[0].profile_read(4096)
+        batches[0].set_profiling(False)
+    for b in batches:
+        b.check_errors()  # an environment that left reference parity would void the measurement
+    for b in batches:
+        b.close()
+
+    single = None
+    if G > 1 and rank == 0 and not use_dist and not args.no_single:
+        # the same workload through one handle on one stream (what --groups 1 reports as the headline)
+        one = make_batches(1)
+        cur = [torch.cuda.current_stream(dev)]
+        k1 = min(args.steps, 200)
+        run(min(args.warmup, 30), 0, one, [table], cur)
+        torch.cuda.synchronize(dev)
+        one[0].set_profiling(True, stride=PROFILE_STRIDE)
+        t1 = time.perf_counter()
+        run(k1, args.warmup, one, [table], cur)
+        torch.cuda.synchronize(dev)
+        d1 = time.perf_counter() - t1
+        km = one[0].profile_read(4096)
+        one[0].check_errors()
+        one[0].close()
+        single = {
+            "steps": k1,
+            "ms_per_step": d1 / k1 * 1e3,
+            "value": E * A * k1 / d1,
+            "kernel_ms_mean": float(km.mean()) if len(km) else None,
+            "achieved": ALGO_BYTES_PER_AGENT_STEP * E * A / (float(km.mean()) * 1e-3) / 1e9 if len(km) else None,
+            "frac": ALGO_BYTES_PER_AGENT_STEP * E * A / (float(km.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS if len(km) else None,
+        }
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -233,14 +307,15 @@ def main() -> None:
         agent_steps = float(world) * E * A * args.steps
         value = agent_steps / dt
         mean_kernel_s = float(kernel_ms.mean()) * 1e-3 if len(kernel_ms) else float("nan")
-        algo_bytes = ALGO_BYTES_PER_AGENT_STEP * E * A
-        achieved = algo_bytes / mean_kernel_s / 1e9
+        algo_bytes = ALGO_BYTES_PER_AGENT_STEP * n * A  # one launch = one group's step
+        per_launch = algo_bytes / mean_kernel_s / 1e9
+        achieved = per_launch * G  # G launches in flight, one per stream
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("envs") == E:
+                if tj.get("envs_per_launch", tj.get("envs")) == n:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -262,6 +337,10 @@ def main() -> None:
                 "full 200-token observations, auto-reset on, 64 reference-generated 62x62 maps",
                 "envs_per_gpu": E,
                 "agents_per_env": A,
+                "groups": G,
+                "stepping": (f"{G} independent groups of {n} environments, one handle and one HIP stream each (the reference's "
+                             "async_factor double buffering): a group's step k+1 follows its own step k only")
+                if G > 1 else "one handle, one stream",
                 "parallelism": f"env-sharded x{world} (independent instances)",
             },
             "roofline": {
@@ -271,7 +350,10 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": step_path + (" (one launch per step: actions, assembler uses, observations, rewards)" if fused else ""),
+                "kernel": step_path + (" (one launch per group and step: actions, assembler uses, observations, rewards)" if fused else ""),
+                "concurrency": G,
+                "envs_per_launch": n,
+                "per_launch_achieved": per_launch,
                 "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
                 "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
                 "kernel_ms_samples": int(len(kernel_ms)),
@@ -287,10 +369,10 @@ def main() -> None:
                     else None,
                 },
             },
+            "single_stream": single,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    batch.close()
     if use_dist:
         dist.destroy_process_group()
 

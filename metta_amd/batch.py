@@ -290,6 +290,13 @@ class MettaGridBatch:
             self.actions.copy_(t.reshape(-1).to(dtype=torch.int32), non_blocking=True)
         self._check(self.L.mg_step(self._h, self._stream()))
 
+    def step_raw(self, actions_ptr: int, stream: int) -> None:
+        """`mg_step_actions` with a device pointer to E*A int32 actions and a HIP stream handle, both as integers: for
+        launch loops that have validated their tensors once (several handles stepped round-robin on their own streams
+        leave about ten microseconds of host time per launch)."""
+        if self.L.mg_step_actions(self._h, actions_ptr, stream):
+            self._check(1)
+
     def step_path(self) -> str:
         """Names of the kernels one step launches for this configuration (diagnostic)."""
         return self.L.mg_step_path(self._h).decode()

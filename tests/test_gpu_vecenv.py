@@ -392,3 +392,52 @@ def test_finished_batch_equals_the_per_environment_calls():
     allv = b.finished_batch(np.arange(E))
     assert allv[0].shape == (E, 24, av.shape[2]) and (allv[5] == 30).all()
     b.close()
+
+
+def test_groups_on_their_own_streams_equal_one_handle():
+    """bench.py steps the environments as G independent groups, one handle and one HIP stream each (the reference's
+    `async_factor` double buffering).  Cutting E environments into groups changes nothing they compute: with the same
+    global environment ids (seed, map), early-reset steps and action columns, the groups' buffers side by side equal
+    the buffers of one handle over all E environments, at every step, through auto-resets."""
+    import torch
+
+    from metta_amd.batch import MettaGridBatch
+    from metta_amd.builder import make_arena
+    from metta_amd.dist import bench_shard
+    from tests.helpers import load_map_pool
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 30
+    pool = load_map_pool()[:8]
+    E, G, A = 64, 4, 24
+    n = E // G
+    seeds, map_ids = bench_shard(0, E, len(pool))
+    early = np.random.RandomState(0).randint(1, 31, size=E).astype(np.uint32)
+    table = torch.randint(0, 5, (16, E * A), device="cuda", dtype=torch.int32)
+
+    def make(lo, hi):
+        b = MettaGridBatch(cfg, hi - lo, pool, device=0, seeds=seeds[lo:hi], map_ids=map_ids[lo:hi])
+        b.set_auto_reset(True, 1)
+        b.set_early_reset(early[lo:hi])
+        return b
+
+    one = make(0, E)
+    groups = [make(q * n, (q + 1) * n) for q in range(G)]
+    tables = [table[:, q * n * A : (q + 1) * n * A].contiguous() for q in range(G)]
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    torch.cuda.synchronize()
+    for t in range(90):
+        row = t % 16
+        one.step(table[row])
+        for q, b in enumerate(groups):
+            b.step_raw(tables[q][row].data_ptr(), streams[q].cuda_stream)
+        if t % 6 == 5 or t == 89:
+            torch.cuda.synchronize()
+            for name in ("observations", "rewards", "terminals", "truncations", "episode_rewards"):
+                whole = getattr(one, name).cpu().numpy()
+                parts = np.concatenate([getattr(b, name).cpu().numpy() for b in groups])
+                assert np.array_equal(whole, parts), f"step {t + 1}: {name}"
+    assert one.finished_summary()[0] == sum(b.finished_summary()[0] for b in groups) >= 2 * E
+    for b in groups + [one]:
+        b.check_errors()
+        b.close()

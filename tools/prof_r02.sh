@@ -4,9 +4,9 @@
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/r02; mkdir -p $O
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-single > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single > /dev/null 2> $O/pmc_fetch.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-single > /dev/null 2> $O/pmc_write.err || exit 1
 python3 - <<'PY'
 import csv, glob, collections, json
 def agg(d):
