@@ -46,22 +46,38 @@ def main():
         cfg = make_combat_stress(A, 256)
         maps = [cfg.game.map_builder.build(np.random.default_rng(i)) for i in range(4)]
         n_act = 8
-    b = MettaGridBatch(cfg, E, maps, device=0, init_obs_passes=2, seeds=list(range(E)), map_ids=[e % len(maps) for e in range(E)])
-    b.set_auto_reset(True, 1)
+    # MG_GROUPS=G: the environments as G independent groups on G streams, like bench.py (default: one handle)
+    import os
+    G = int(os.environ.get("MG_GROUPS", "1"))
+    n = E // G
+    bs = [MettaGridBatch(cfg, n, maps, device=0, init_obs_passes=2, seeds=list(range(q * n, (q + 1) * n)),
+                         map_ids=[e % len(maps) for e in range(q * n, (q + 1) * n)]) for q in range(G)]  # fmt: skip
+    for b in bs:
+        b.set_auto_reset(True, 1)
     table = torch.randint(0, n_act, (16, E * A), device="cuda", dtype=torch.int32)
-    for t in range(10):
-        b.step(table[t % 16])
+    tabs = [table[:, q * n * A : (q + 1) * n * A].contiguous() for q in range(G)]
+    sts = [torch.cuda.Stream() for _ in range(G)] if G > 1 else [torch.cuda.current_stream()]
+    ptrs = [[tb[r].data_ptr() for r in range(16)] for tb in tabs]
+
+    def run(k):
+        for t in range(k):
+            for q, b in enumerate(bs):
+                b.step_raw(ptrs[q][t % 16], sts[q].cuda_stream)
+
     torch.cuda.synchronize()
-    b.set_profiling(True)
+    run(10)
+    torch.cuda.synchronize()
+    for b in bs:
+        b.set_profiling(True)
     t0 = time.perf_counter()
-    for t in range(steps):
-        b.step(table[t % 16])
+    run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms = b.profile_read(4096)
-    print(json.dumps({"workload": which, "envs": E, "agents_per_env": A, "steps": steps, "ms_per_step": dt / steps * 1e3,
+    ms = np.concatenate([b.profile_read(4096) for b in bs])
+    print(json.dumps({"workload": which, "envs": E, "agents_per_env": A, "groups": G, "steps": steps, "ms_per_step": dt / steps * 1e3,
                       "kernel_ms_mean": float(ms.mean()), "agent_steps_per_s": E * A * steps / dt}))
-    b.close()
+    for b in bs:
+        b.close()
 
 
 def mapgen_bench():
