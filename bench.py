@@ -235,11 +235,9 @@ def main() -> None:
         # (tensors validated here once; the loop hands the library raw pointers and stream handles)
         assert all(tb.dtype == torch.int32 and tb.is_contiguous() and tb.shape[1] == b.actions.numel() for b, tb in zip(bs, tbs))
         ptrs = [[tb[r].data_ptr() for r in range(64)] for tb in tbs]
-        calls = [(b.step_raw, ptrs[q], sts[q].cuda_stream) for q, b in enumerate(bs)]
+        step = MettaGridBatch.group_stepper(bs, ptrs, [st.cuda_stream for st in sts])  # one library call per step
         for t in range(k):
-            row = (base + t) % 64
-            for step_raw, p, sh in calls:
-                step_raw(p[row], sh)
+            step((base + t) % 64)
             if use_dist and (base + t) % 128 == 127:
                 reduce_summary()
 

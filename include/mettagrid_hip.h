@@ -146,6 +146,13 @@ int mg_step(mg_handle* h, void* stream);
  * `MettaGridPufferEnv.step` (mettagrid_puffer_env.py:166-169). */
 int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream);
 
+/* mg_step_actions for n handles in one call: hs[i] steps with device_actions[i] on streams[i].  The handles are the
+ * independent environment groups of an asynchronous vecenv (the reference's `async_factor` groups,
+ * metta/rl/training/training_environment.py:45-46,151-170; pufferlib vector.py:415-503: each group's step is ordered
+ * on its own stream only); one call instead of n keeps the host cost of a step below the kernels' duration when the
+ * groups are many and small.  Stops at the first failing handle. */
+int mg_step_groups(int n, mg_handle* const* hs, const int32_t* const* device_actions, void* const* streams);
+
 /* Allocation-free step.  No counterpart in the reference: it is for callers that cannot allocate -- code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and results as mg_step /
  * mg_step_actions (`device_actions` NULL = the handle's own action buffer), but the per-step hand-over buffers

@@ -297,6 +297,22 @@ class MettaGridBatch:
         if self.L.mg_step_actions(self._h, actions_ptr, stream):
             self._check(1)
 
+    @staticmethod
+    def group_stepper(batches, action_rows, streams):
+        """`mg_step_groups` for a fixed set of handles: returns `step(row)` that steps batches[q] with the device
+        actions at action_rows[q][row] (integer pointers) on streams[q] (HIP stream handles), all in one library call."""
+        L, n = batches[0].L, len(batches)
+        hs = (ct.c_void_p * n)(*[ct.cast(b._h, ct.c_void_p).value for b in batches])
+        sts = (ct.c_void_p * n)(*[int(s) for s in streams])
+        rows = [(ct.c_void_p * n)(*[int(action_rows[q][r]) for q in range(n)]) for r in range(len(action_rows[0]))]
+        check = batches[0]._check
+
+        def step(row: int) -> None:
+            if L.mg_step_groups(n, hs, rows[row], sts):
+                check(1)
+
+        return step
+
     def step_path(self) -> str:
         """Names of the kernels one step launches for this configuration (diagnostic)."""
         return self.L.mg_step_path(self._h).decode()

@@ -1247,6 +1247,15 @@ int mg_step_actions(mg_handle* h, const int32_t* device_actions, void* stream) {
   return mg_step_impl(h, device_actions, stream);
 }
 
+int mg_step_groups(int n, mg_handle* const* hs, const int32_t* const* device_actions, void* const* streams) {
+  if (n < 0 || (n > 0 && (!hs || !device_actions || !streams))) return fail("mg_step_groups: NULL argument");
+  for (int i = 0; i < n; i++) {
+    if (!device_actions[i]) return fail("mg_step_groups: NULL action buffer");
+    if (int rc = mg_step_impl(hs[i], device_actions[i], streams[i])) return rc;
+  }
+  return 0;
+}
+
 int mg_step_noalloc(mg_handle* h, const int32_t* device_actions, void* stream) {
   return mg_step_impl(h, device_actions, stream, true);  // NULL actions = the handle's own action buffer
 }

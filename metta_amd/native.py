@@ -64,6 +64,7 @@ SYMBOLS = {
     "mg_reset": (ct.c_int, [_vp, _i32p, ct.c_int, _u32p, _i32p, _vp]),
     "mg_step": (ct.c_int, [_vp, _vp]),
     "mg_step_actions": (ct.c_int, [_vp, _vp, _vp]),
+    "mg_step_groups": (ct.c_int, [ct.c_int, ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_void_p)]),
     "mg_step_noalloc": (ct.c_int, [_vp, _vp, _vp]),
     "mg_status_buffer": (ct.c_int, [_vp, ct.POINTER(ct.POINTER(ct.c_uint32)), _i32p]),
     "mg_check_errors": (ct.c_int, [_vp, _vp]),

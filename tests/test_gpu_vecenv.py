@@ -426,11 +426,17 @@ def test_groups_on_their_own_streams_equal_one_handle():
     tables = [table[:, q * n * A : (q + 1) * n * A].contiguous() for q in range(G)]
     streams = [torch.cuda.Stream() for _ in range(G)]
     torch.cuda.synchronize()
+    # bench.py's launch loop: one `mg_step_groups` call per step; every third step through the per-handle form
+    step_all = MettaGridBatch.group_stepper(groups, [[tb[r].data_ptr() for r in range(16)] for tb in tables],
+                                            [st.cuda_stream for st in streams])  # fmt: skip
     for t in range(90):
         row = t % 16
         one.step(table[row])
-        for q, b in enumerate(groups):
-            b.step_raw(tables[q][row].data_ptr(), streams[q].cuda_stream)
+        if t % 3 == 2:
+            for q, b in enumerate(groups):
+                b.step_raw(tables[q][row].data_ptr(), streams[q].cuda_stream)
+        else:
+            step_all(row)
         if t % 6 == 5 or t == 89:
             torch.cuda.synchronize()
             for name in ("observations", "rewards", "terminals", "truncations", "episode_rewards"):
