@@ -364,3 +364,50 @@ def test_write_map_slot_on_a_generated_pool_and_its_errors():
     with pytest.raises(RuntimeError, match="differ in size"):
         b2.write_map_slot(0, ref[1])
     b2.close()
+
+
+def test_clipper_on_a_refreshed_device_pool_vs_oracle():
+    """A Clipper over device-generated maps: every refresh rebuilds the slot's template with the template's own clipper,
+    every restart rebuilds the environment's (stations that start clipped draw their unclipping protocol from the
+    environment's seed; weights and length scale follow the new map)."""
+    from metta_amd.config import ClipperConfig, ProtocolConfig
+    from oracle.mg_oracle import make_oracle_env
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 20
+    cfg.game.clipper = ClipperConfig(
+        unclipping_protocols=[ProtocolConfig(input_resources={"ore_red": 1}, cooldown=2), ProtocolConfig(input_resources={"battery_red": 1}, cooldown=1)],
+        clip_period=2, scaled_cutoff_distance=2,
+    )  # fmt: skip
+    cfg.game.objects["generator_red"].start_clipped = True
+    cfg.game.objects["lasery"].clip_immune = True
+    comp = compile_game(cfg, init_obs_passes=2)
+    spec = cfg.game.map_builder.device_spec()
+    E, A = 3, 24
+    seeds, cur_map = [61, 62, 63], [0, 1, 2]
+    b = _gen_batch(cfg, E, spec, 2 * E, seed=12, seeds=seeds, map_ids=cur_map)
+    b.set_auto_reset(True, E)
+    oras = [make_oracle_env(comp, b.get_map(m), s) for s, m in zip(seeds, cur_map)]
+    _compare_step(b, oras, 0, A)
+    rs = np.random.RandomState(4)
+    for t in range(1, 110):
+        if t % 10 == 0:
+            b.refresh_maps()
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                cur_map[e] = (cur_map[e] + E) % (2 * E)
+                oras[e] = make_oracle_env(comp, b.get_map(cur_map[e]), seeds[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+        if t % 15 == 0:
+            _compare_state(b, oras, t)
+            for e, o in enumerate(oras):
+                ls, w = o.clipper_state()
+                dls, dw = b.clipper_state(e)
+                assert dls == ls and np.array_equal(dw, w), f"step {t} env {e}: clipper state"
+    st = b.assembler_state(0)
+    assert (st[:, 4] >= 2).any(), "stations were clipped"
+    b.check_errors()
+    b.close()
