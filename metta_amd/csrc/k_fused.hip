@@ -24,7 +24,16 @@
 
 // Built twice: as is, and through k_fused_nomod.hip with MG_NO_MODIFIERS (configurations without inventory-limit
 // modifiers, e.g. arena and navigation: the use code then needs far fewer registers).
-#ifdef MG_NO_MODIFIERS
+// and a third time (k_fused_nomod_o7.hip) for 7 instead of 8 waves per SIMD: 72 registers, no vector spills, 14
+// workgroups per CU -- the better build whenever the launch is not exactly one round of 16 workgroups per CU (small
+// groups stepped on several streams, or more environments than one round holds).
+#if defined(MG_NO_MODIFIERS) && defined(MG_FUSED_O7)
+#define mg_step_fused_kernel mg_step_fused_nomod_o7_kernel
+#define mg_launch_fused mg_launch_fused_nomod_o7
+#define mg_fused_lds_bytes mg_fused_lds_bytes_nomod_o7
+#define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod_o7
+#define MG_FUSED_OCC 7
+#elif defined(MG_NO_MODIFIERS)
 #define mg_step_fused_kernel mg_step_fused_nomod_kernel
 #define mg_launch_fused mg_launch_fused_nomod
 #define mg_fused_lds_bytes mg_fused_lds_bytes_nomod
@@ -470,7 +479,10 @@ __device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* 
 }
 
 template <bool DCL>
-__global__ __launch_bounds__(MG_FUSED_THREADS, 8) void mg_step_fused_kernel(KArgs a0) {
+#ifndef MG_FUSED_OCC
+#define MG_FUSED_OCC 8  // waves per SIMD the register budget allows (64 VGPRs): 16 workgroups of 2 waves per CU
+#endif
+__global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_kernel(KArgs a0) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x, nt = MG_FUSED_THREADS;
   const int lane = tid & 63, wave = tid >> 6;

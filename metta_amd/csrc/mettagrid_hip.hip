@@ -7,7 +7,7 @@
 // own translation units (shared device code: mg_kernels.h, mg_sim.h):
 //   k_fused.hip        mg_step_fused_kernel  the whole step of one environment in one 2-wave workgroup (attack-free
 //   k_fused_nomod.hip                        configs, A <= 64: arena, navigation); the second file is the same source
-//                                            built without inventory-limit modifiers
+//   k_fused_nomod_o7.hip                     built without inventory-limit modifiers, the third that for 7 waves per SIMD
 //   k_act_fast.hip     mg_act_fast_kernel    three-launch variant of the same class (MG_NO_FUSED=1): wave-parallel actions,
 //   k_uses.hip         mg_uses_kernel        the assembler uses handed over by it,
 //   k_obs.hip          mg_obs_kernel         token lists, observation rows, rewards, flags (also the general path's second launch)
@@ -161,6 +161,7 @@ struct mg_handle {
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
   bool fused_dcl = false, cells8 = false;
   bool no_modifiers = false;       // no group / chest has inventory-limit modifiers: the leaner build of the fused kernel
+  bool fused_o7 = false;           // ... and its 7-waves-per-SIMD build (see below)
   bool big = false;                // map tile too large for LDS: grid (and, for obs/reset, agent records) in HBM
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -640,6 +641,15 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         h->no_modifiers = !mg_has_modifiers(c);
         HIPCHK(mg_raise_lds_cap_fused((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
+        HIPCHK(mg_raise_lds_cap_fused_nomod_o7((int)LDS_MAX));
+        // 16 workgroups per CU (64 registers, some spilled) pay when the environments are exactly one round of them;
+        // with fewer (groups stepped on several streams fill each other's tails) or more (several rounds anyway) the
+        // 14-per-CU build without vector spills is the faster one.  MG_FUSED_O7=0/1 overrides.
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, h->device));
+        const long long cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        h->fused_o7 = !(h->E > 14 * cus && h->E <= 16 * cus);
+        if (const char* o7 = getenv("MG_FUSED_O7")) h->fused_o7 = o7[0] == '1';
       }
     }
   }
@@ -1216,7 +1226,8 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
     const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
     if (h->fused) {
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
-      if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
+      if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
+      else if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
       else mg_launch_fused(kg, n, h->lds_fused, h->fused_dcl, st);
     } else {
       if (k.fast) {
@@ -1380,7 +1391,7 @@ int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
 
 const char* mg_step_path(mg_handle* h) {
   if (!h || !h->maps_set) return "";
-  if (h->fused) return h->no_modifiers ? "mg_step_fused_nomod_kernel" : "mg_step_fused_kernel";
+  if (h->fused) return h->no_modifiers ? (h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel") : "mg_step_fused_kernel";
   if (h->k.fast) return "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel";
   return "mg_act_kernel + mg_obs_kernel";
 }
