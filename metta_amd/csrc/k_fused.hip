@@ -63,7 +63,7 @@ __host__ __device__ inline size_t mg_carve_fused(unsigned char* base, Lds* l, in
   if (u_b < (size_t)MG_FUSED_SLOTS * 96 * 4) u_b = (size_t)MG_FUSED_SLOTS * 96 * 4;
   if (u_b < 624 * 4) u_b = 624 * 4;
   size_t u = take(u_b);
-  const int WS = (NP + 63) & ~63;
+  const int WS = NP <= 128 ? 128 : ((NP + 63) & ~63);  // (two full rounds: the encoder reads them without a bounds test)
   size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP);
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16);
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A);

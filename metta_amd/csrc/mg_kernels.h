@@ -395,6 +395,33 @@ __device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, c
   }
 }
 
+// One map of the byte pool behind a buffer descriptor: `buffer_load_ubyte` takes the cell offset as it is (scalar base
+// in the descriptor, no address arithmetic on the vector unit) and returns 0 for offsets outside the map, so cells
+// outside it need no address of their own.
+struct MgByteMap {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc;
+#else
+  const uint8_t* p;
+#endif
+};
+__device__ __forceinline__ MgByteMap mg_byte_map(const uint8_t* p, int bytes) {
+  MgByteMap m;
+#if defined(__HIP_DEVICE_COMPILE__)
+  m.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);  // raw buffer, gfx9 data format word
+#else
+  m.p = p;
+#endif
+  return m;
+}
+__device__ __forceinline__ uint32_t mg_byte_at(const MgByteMap& m, uint32_t off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(m.rsrc, (int)off, 0, 0);
+#else
+  return m.p[off];
+#endif
+}
+
 // The same lookups without an occupancy tile in LDS (fused kernel): the static layer comes from the byte map of the
 // pool in HBM (L2-resident: every environment playing the map reads the same few KB), and the agents of the environment
 // that stand inside the window are scattered over the window cells through a small per-wave LDS buffer `ws` (all zero
@@ -402,7 +429,7 @@ __device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, c
 template <int NR>
 __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
                                                         const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
-                                                        uint32_t& rc, const uint32_t posj, uint8_t* ws) {
+                                                        uint32_t& rc, const uint32_t posj, uint8_t* ws, const MgByteMap& gm) {
   const int H = ec.H, W = ec.W, P = ec.P;
   rc = *(const uint32_t*)me;
   const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
@@ -412,14 +439,14 @@ __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Ld
     const int p = q * 64 + lane;
     const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
     const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W;
-    const uint32_t v = l.gmap[ok ? __mul24(r, W) + c : 0];
+    const uint32_t v = mg_byte_at(gm, (uint32_t)(__mul24(r, W) + c));  // (whatever it reads when !ok is masked)
     cvs[q] = ok ? v : 0u;
   }
   const int jr = (int)(posj & 0xFFFF) - ar, jc = (int)(posj >> 16) - ac;
   const bool inwin = lane < a.A && jr >= -ec.hr && jr <= ec.hr && jc >= -ec.wr && jc <= ec.wr;
   int pj = 0;
   if (inwin) {
-    pj = l.ipat[(jr + ec.hr) * ec.ow + jc + ec.wr];
+    pj = l.ipat[__mul24(jr + ec.hr, ec.ow) + jc + ec.wr];
     ws[pj] = (uint8_t)(lane + 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -428,7 +455,8 @@ __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Ld
 #pragma unroll
   for (int q = 0; q < NR; q++) {
     const int p = q * 64 + lane;
-    aj[q] = p < l.WS ? ws[p] : 0u;
+    // (the headline template reads two rounds: the buffer holds at least 128 entries, mg_carve_fused)
+    aj[q] = (NR <= 2 || p < l.WS) ? ws[p] : 0u;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -552,6 +580,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   uint2 carry = make_uint2(0, 0);
   uint32_t posj = 0;
   if (DIRECT && lane < a.A) posj = *(const uint32_t*)&l.ag[lane];
+  const MgByteMap gm = mg_byte_map(DIRECT ? l.gmap : nullptr, DIRECT ? a.HW8 : 0);
   // per-agent offsets are carried along instead of multiplied out (v_mul_lo_u32 runs at quarter rate)
   uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
   const DAgent* me0 = l.ag + wave * group;
@@ -562,7 +591,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
 #pragma unroll
     for (int h = 0; h < group; h++) {
       if (DIRECT)
-        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS);
+        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS, gm);
       else
         mg_window_lookup<NR, PAIRS, CT>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
     }
