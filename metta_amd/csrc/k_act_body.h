@@ -24,7 +24,9 @@
 #define MG_WITH_CLIPPER  // (mg_restart_env rebuilds the environment's clipper)
 #include "mg_kernels.h"
 
+#ifndef MG_ACT_MAX_THREADS
 #define MG_ACT_MAX_THREADS 1024
+#endif
 #define MG_ACT_TMP_SLOTS 32   // assembler uses executed concurrently in one round (scratch slots)
 #define MG_ACT_TMP_INTS 128   // 96 + 32 input holders (mg_assembler_use)
 
