@@ -257,6 +257,40 @@ def test_fuzz_clipper_vs_oracle(seed):
     b.close()
 
 
+def test_arena_with_limit_modifiers_runs_the_fused_kernel_with_them():
+    """Inventory-limit modifiers (inventory.cpp:87-158: a held resource raises a limit, losing it drops the excess) on an
+    otherwise wave-parallel configuration: the fused kernel's build WITH the nested limit enforcement
+    (`mg_step_fused_kernel`; arena and navigation themselves run the build without it)."""
+    from metta_amd.config import ResourceLimitsConfig
+
+    cfg = make_arena(24)
+    ag = cfg.game.agent
+    ag.inventory.limits["ore"] = ResourceLimitsConfig(limit=2, resources=["ore_red"], modifiers={"battery_red": 2})
+    ag.inventory.limits["bat"] = ResourceLimitsConfig(limit=3, resources=["battery_red"], modifiers={"heart": 1})
+    ag.inventory.initial = {"ore_red": 2, "battery_red": 1}
+    maps = load_map_pool()[:4]
+    E, A = 8, 24
+    seeds = list(range(200, 200 + E))
+    map_ids = [e % len(maps) for e in range(E)]
+    b = _batch(cfg, maps, E, seeds, map_ids)
+    assert b.step_path() == "mg_step_fused_kernel"
+    comp, oras = _oracles(cfg, maps, seeds, map_ids)
+    _compare_step(b, oras, 0, A)
+    rs = np.random.RandomState(9)
+    for t in range(1, 301):
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        b.step(acts.reshape(-1))
+        for e, o in enumerate(oras):
+            o.step(acts[e])
+        _compare_step(b, oras, t, A)
+        if t % 100 == 0:
+            _compare_state(b, oras, t)
+    st = b.agent_state(0)
+    assert (st[:, 8] > 0).any()
+    b.check_errors()
+    b.close()
+
+
 def test_more_resources_than_the_wide_build_holds_is_an_error():
     cfg = rand_cfg(np.random.RandomState(1), device_safe=True, num_resources=33)
     maps = [cfg.game.map_builder.build(np.random.default_rng(1))]
