@@ -33,6 +33,12 @@
 #define mg_fused_lds_bytes mg_fused_lds_bytes_nomod_o7
 #define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod_o7
 #define MG_FUSED_OCC 7
+#elif defined(MG_FUSED_O6)  // (k_fused_o6.hip: the build with modifiers needs 80 registers to stop spilling)
+#define mg_step_fused_kernel mg_step_fused_o6_kernel
+#define mg_launch_fused mg_launch_fused_o6
+#define mg_fused_lds_bytes mg_fused_lds_bytes_o6
+#define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_o6
+#define MG_FUSED_OCC 6
 #elif defined(MG_NO_MODIFIERS)
 #define mg_step_fused_kernel mg_step_fused_nomod_kernel
 #define mg_launch_fused mg_launch_fused_nomod

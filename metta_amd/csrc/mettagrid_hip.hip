@@ -161,7 +161,7 @@ struct mg_handle {
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
   bool fused_dcl = false, cells8 = false;
   bool no_modifiers = false;       // no group / chest has inventory-limit modifiers: the leaner build of the fused kernel
-  bool fused_o7 = false;           // ... and its 7-waves-per-SIMD build (see below)
+  bool fused_o7 = false;           // ... the builds with a larger register budget (7 waves per SIMD; 6 with modifiers), see below
   bool big = false;                // map tile too large for LDS: grid (and, for obs/reset, agent records) in HBM
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
   hipStream_t aux[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -642,6 +642,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         HIPCHK(mg_raise_lds_cap_fused((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod_o7((int)LDS_MAX));
+        HIPCHK(mg_raise_lds_cap_fused_o6((int)LDS_MAX));
         // 16 workgroups per CU (64 registers, some spilled) pay when the environments are exactly one round of them;
         // with fewer (groups stepped on several streams fill each other's tails) or more (several rounds anyway) the
         // 14-per-CU build without vector spills is the faster one.  MG_FUSED_O7=0/1 overrides.
@@ -1228,6 +1229,7 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
       if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
+      else if (h->fused_o7) mg_launch_fused_o6(kg, n, h->lds_fused, h->fused_dcl, st);
       else mg_launch_fused(kg, n, h->lds_fused, h->fused_dcl, st);
     } else {
       if (k.fast) {
@@ -1391,7 +1393,9 @@ int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
 
 const char* mg_step_path(mg_handle* h) {
   if (!h || !h->maps_set) return "";
-  if (h->fused) return h->no_modifiers ? (h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel") : "mg_step_fused_kernel";
+  if (h->fused)
+    return h->no_modifiers ? (h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel")
+                           : (h->fused_o7 ? "mg_step_fused_o6_kernel" : "mg_step_fused_kernel");
   if (h->k.fast) return "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel";
   return "mg_act_kernel + mg_obs_kernel";
 }

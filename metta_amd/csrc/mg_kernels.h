@@ -1195,6 +1195,8 @@ void mg_launch_fused_nomod(const KArgs& k, unsigned n, size_t lds, bool dcl, hip
 hipError_t mg_raise_lds_cap_fused_nomod(int cap);
 void mg_launch_fused_nomod_o7(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_nomod_o7.hip
 hipError_t mg_raise_lds_cap_fused_nomod_o7(int cap);
+void mg_launch_fused_o6(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_o6.hip
+hipError_t mg_raise_lds_cap_fused_o6(int cap);
 // the cap on dynamic LDS is a per-function setting shared by every handle of the process
 hipError_t mg_raise_lds_cap_uses(int cap);
 hipError_t mg_raise_lds_cap_act(int cap);

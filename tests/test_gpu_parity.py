@@ -273,7 +273,7 @@ def test_arena_with_limit_modifiers_runs_the_fused_kernel_with_them():
     seeds = list(range(200, 200 + E))
     map_ids = [e % len(maps) for e in range(E)]
     b = _batch(cfg, maps, E, seeds, map_ids)
-    assert b.step_path() == "mg_step_fused_kernel"
+    assert b.step_path() == "mg_step_fused_o6_kernel"  # (8 environments: the larger register budget)
     comp, oras = _oracles(cfg, maps, seeds, map_ids)
     _compare_step(b, oras, 0, A)
     rs = np.random.RandomState(9)
