@@ -27,7 +27,16 @@
 // and a third time (k_fused_nomod_o7.hip) for 7 instead of 8 waves per SIMD: 72 registers, no vector spills, 14
 // workgroups per CU -- the better build whenever the launch is not exactly one round of 16 workgroups per CU (small
 // groups stepped on several streams, or more environments than one round holds).
-#if defined(MG_NO_MODIFIERS) && defined(MG_FUSED_O7)
+#if defined(MG_NO_MODIFIERS) && defined(MG_FUSED_W1)
+// (k_fused_nomod_w1.hip: ONE wave per environment, for environments of a few agents -- navigation has 4 -- where a
+// second wave only repeats the scalar work and idles through the single-wave phases)
+#define mg_step_fused_kernel mg_step_fused_nomod_w1_kernel
+#define mg_launch_fused mg_launch_fused_nomod_w1
+#define mg_fused_lds_bytes mg_fused_lds_bytes_nomod_w1
+#define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod_w1
+#define MG_FUSED_OCC 7
+#define MG_FUSED_THREADS 64
+#elif defined(MG_NO_MODIFIERS) && defined(MG_FUSED_O7)
 #define mg_step_fused_kernel mg_step_fused_nomod_o7_kernel
 #define mg_launch_fused mg_launch_fused_nomod_o7
 #define mg_fused_lds_bytes mg_fused_lds_bytes_nomod_o7
@@ -45,7 +54,9 @@
 #define mg_fused_lds_bytes mg_fused_lds_bytes_nomod
 #define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod
 #endif
+#ifndef MG_FUSED_THREADS
 #define MG_FUSED_THREADS 128
+#endif
 #define MG_FUSED_SLOTS 4  // assembler uses resolved concurrently (scratch slots of 96 ints)
 
 template <bool FILL>
@@ -397,7 +408,7 @@ __device__ MG_FUSED_USES_ATTR void mg_fused_uses(const KArgs& a, const Lds& l, C
   for (int rd = 0; rd <= max_round; rd++) {
     for (int q0 = 0; q0 < count; q0 += MG_FUSED_SLOTS) {
       const int q = q0 + lane;
-      if (lane < MG_FUSED_SLOTS && (lane & 1) == wsel && q < count && rounds[q] == rd) {
+      if (lane < MG_FUSED_SLOTS && (MG_FUSED_THREADS == 64 || (lane & 1) == wsel) && q < count && rounds[q] == rd) {
         const uint8_t* rec = recs + q * 32;
         const int actor = rec[0], nn = rec[1], asm_idx = rec[2] | (rec[3] << 8);
         const int act = *(const int*)(rec + 4);
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       if (tid == 0) l.mtnext[623] = mt_mix(mt[623], l.mtnext[0], l.mtnext[396]);
     }
     env.step += 1;
-    actor = (a.diag & 4096) ? 0 : (int)(blockIdx.x & 1u);  // spread the single-wave phases over the SIMDs
+    actor = (MG_FUSED_THREADS == 64 || (a.diag & 4096)) ? 0 : (int)(blockIdx.x & 1u);  // spread the single-wave phases over the SIMDs
     __syncthreads();
     MG_STAMP(1);
   }

@@ -7,7 +7,8 @@
 // own translation units (shared device code: mg_kernels.h, mg_sim.h):
 //   k_fused.hip        mg_step_fused_kernel  the whole step of one environment in one 2-wave workgroup (attack-free
 //   k_fused_nomod.hip                        configs, A <= 64: arena, navigation); the second file is the same source
-//   k_fused_nomod_o7.hip                     built without inventory-limit modifiers, the third that for 7 waves per SIMD
+//   k_fused_nomod_o7.hip                     built without inventory-limit modifiers, the third that for 7 waves per SIMD;
+//   k_fused_o6.hip, k_fused_nomod_w1.hip     with modifiers for 6 waves per SIMD; one wave per environment (<= 8 agents)
 //   k_act_fast.hip     mg_act_fast_kernel    three-launch variant of the same class (MG_NO_FUSED=1): wave-parallel actions,
 //   k_uses.hip         mg_uses_kernel        the assembler uses handed over by it,
 //   k_obs.hip          mg_obs_kernel         token lists, observation rows, rewards, flags (also the general path's second launch)
@@ -156,7 +157,8 @@ struct mg_handle {
   KArgs k;
   std::vector<void*> allocs;
   std::vector<void*> map_allocs;
-  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0, lds_fused = 0;
+  size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0, lds_fused = 0, lds_fused_w1 = 0;
+  bool fused_w1 = false;  // the one-wave-per-environment build of the fused kernel (few agents, no modifiers)
   bool dc_lds = false;
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
   bool fused_dcl = false, cells8 = false;
@@ -643,6 +645,12 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod_o7((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_o6((int)LDS_MAX));
+        HIPCHK(mg_raise_lds_cap_fused_nomod_w1((int)LDS_MAX));
+        // A few agents per environment (navigation: 4): one wave does the whole step; a second one would repeat the
+        // scalar work and wait through the action and use phases.  MG_FUSED_W1=0/1 overrides.
+        h->lds_fused_w1 = mg_fused_lds_bytes_nomod_w1(k, h->fused_dcl);
+        h->fused_w1 = h->no_modifiers && c.A <= 8 && h->lds_fused_w1 <= LDS_MAX;
+        if (const char* w1 = getenv("MG_FUSED_W1")) h->fused_w1 = h->no_modifiers && w1[0] == '1' && h->lds_fused_w1 <= LDS_MAX;
         // 16 workgroups per CU (64 registers, some spilled) pay when the environments are exactly one round of them;
         // with fewer (groups stepped on several streams fill each other's tails) or more (several rounds anyway) the
         // 14-per-CU build without vector spills is the faster one.  MG_FUSED_O7=0/1 overrides.
@@ -1227,7 +1235,8 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
     const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
     if (h->fused) {
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
-      if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
+      if (h->no_modifiers && h->fused_w1) mg_launch_fused_nomod_w1(kg, n, h->lds_fused_w1, h->fused_dcl, st);
+      else if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->fused_o7) mg_launch_fused_o6(kg, n, h->lds_fused, h->fused_dcl, st);
       else mg_launch_fused(kg, n, h->lds_fused, h->fused_dcl, st);
@@ -1394,7 +1403,7 @@ int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
 const char* mg_step_path(mg_handle* h) {
   if (!h || !h->maps_set) return "";
   if (h->fused)
-    return h->no_modifiers ? (h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel")
+    return h->no_modifiers ? (h->fused_w1 ? "mg_step_fused_nomod_w1_kernel" : h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel")
                            : (h->fused_o7 ? "mg_step_fused_o6_kernel" : "mg_step_fused_kernel");
   if (h->k.fast) return "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel";
   return "mg_act_kernel + mg_obs_kernel";

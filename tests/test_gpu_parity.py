@@ -65,8 +65,10 @@ def _compare_state(b, oras, t):
 
 @pytest.mark.parametrize(
     "path_env",
-    [{}, {"MG_DIAG": "8"}, {"MG_FORCE_GENERAL": "1"}, {"MG_FUSED_O7": "0"}, {"MG_FUSED_O7": "0", "MG_DIAG": "8"}, {"MG_NO_FUSED": "1"}],
-    ids=["fast", "fast-serial-redraw", "general", "fused-8-waves-build", "fused-8-waves-build-serial-redraw", "three-launch"],
+    [{}, {"MG_DIAG": "8"}, {"MG_FORCE_GENERAL": "1"}, {"MG_FUSED_O7": "0"}, {"MG_FUSED_O7": "0", "MG_DIAG": "8"}, {"MG_NO_FUSED": "1"},
+     {"MG_FUSED_W1": "1"}, {"MG_FUSED_W1": "1", "MG_DIAG": "8"}],
+    ids=["fast", "fast-serial-redraw", "general", "fused-8-waves-build", "fused-8-waves-build-serial-redraw", "three-launch",
+         "fused-one-wave-build", "fused-one-wave-build-serial-redraw"],
 )
 def test_arena_vs_oracle(path_env, monkeypatch):
     """The same comparison through each act-kernel path: the wave-parallel fast kernel (+ the assembler-use
