@@ -233,6 +233,32 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
   const uint32_t Tm = mover ? (((uint32_t)tr << 16) | (uint32_t)tc) : 0xFFFFFFFFu;
 
   // ---- fixed point over move success ----------------------------------------------------------------------
+  // (agent masks: 32 bits wide when the agents fit -- half the vector instructions of the 64-bit form)
+  bool m = mover;
+#if defined(MG_FUSED_O7) || defined(MG_FUSED_O6) || defined(MG_FUSED_W1)
+  auto fixed_point = [&](auto zero) {
+    typedef decltype(zero) mask_t;
+    mask_t occ = 0, tgt = 0, lower = 0;
+    for (int j = 0; j < A; j++) {
+      const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
+      const uint32_t Tj = (uint32_t)__builtin_amdgcn_readlane((int)Tm, j);
+      const int rj = __builtin_amdgcn_readlane(rank, j);
+      const mask_t bit = (mask_t)1 << j;
+      if (Pj == Tm) occ |= bit;
+      if (Tj == Tm && j != lane) tgt |= bit;
+      if (rj < rank) lower |= bit;
+    }
+    for (int it = 0; it <= A; it++) {
+      const mask_t before = lower & (mask_t)__ballot(m);  // moved (away / in) before my turn
+      const bool nm = mover && (occ & ~before) == 0 && (tgt & before) == 0;
+      const bool changed = nm != m;
+      m = nm;
+      if (__ballot(changed) == 0) break;
+    }
+  };
+  if (A <= 32) fixed_point((uint32_t)0);
+  else fixed_point((unsigned long long)0);
+#else  // (the 64-register builds keep the one 64-bit form: a second copy of the loop costs them on one stream, 0.064 -> 0.066 ms)
   unsigned long long occ = 0, tgt = 0, lower = 0;
   for (int j = 0; j < A; j++) {
     const uint32_t Pj = (uint32_t)__builtin_amdgcn_readlane((int)P, j);
@@ -243,7 +269,6 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
     if (Tj == Tm && j != lane) tgt |= bit;
     if (rj < rank) lower |= bit;
   }
-  bool m = mover;
   for (int it = 0; it <= A; it++) {
     const unsigned long long before = lower & __ballot(m);  // moved (away / in) before my turn
     const bool nm = mover && (occ & ~before) == 0 && (tgt & before) == 0;
@@ -251,6 +276,7 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
     m = nm;
     if (__ballot(changed) == 0) break;
   }
+#endif
 
   // ---- assembler uses, in rank order, with the ring as it stood at that moment ------------------------------
   bool user = bump;
