@@ -172,7 +172,13 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when its communicator comes up: stdout carries the one JSON line only,
+        # so file descriptor 1 points at stderr until the warm-up's first all-reduce is through
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
@@ -245,6 +251,10 @@ def main() -> None:
     if use_dist:
         reduce_summary()  # communicator set-up and first-use costs stay out of the timed region
     sync_all()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     # HIP events around every 8th step of the timed region: an event pair per step costs ~7 % of the step it times
     for b in batches:
         b.set_profiling(True, stride=PROFILE_STRIDE)
