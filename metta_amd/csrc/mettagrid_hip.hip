@@ -535,6 +535,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     ts_[1] += 4; ts_[2] += 4; ts_[3] += 4;
   }
   for (int i = 0; i < 4; i++) ts_[i] = std::max(ts_[i], h->ts_need[i]);
+  for (int i = 0; i < 4; i++)  // the encoder's scan adds 64 counts in 16 bits (mg_encode_agent)
+    if (ts_[i] > 1000) return fail("mg_set_maps: an object kind shows " + std::to_string(ts_[i]) + " tokens (limit 1000)");
   int TSW = ts_[0], TSA = ts_[1], TSS = ts_[2], TSC = ts_[3];
   if (TSW > 255 || TSA > 255 || TSS > 255 || TSC > 255) return fail("mg_set_maps: an object can show more than 255 tokens");
   TSW = (TSW + 3) & ~3; TSA = (TSA + 3) & ~3; TSS = (TSS + 3) & ~3; TSC = (TSC + 3) & ~3;  // lists are read 4 tokens (8 bytes) at a time

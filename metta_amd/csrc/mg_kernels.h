@@ -507,13 +507,31 @@ __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, con
     }
   }
   base = __builtin_amdgcn_readfirstlane(base);
+  // Two rounds share one scan: both counts ride in one register, 16 bits each.  (An object has at most one token per
+  // feature id and one per tag id, under 512 in all; mg_set_maps refuses lists of more than 1000: 64 stay below 2^16.)
+  uint32_t ex2 = 0, tot2 = 0;
+  if (NR == 2) {
+    const uint32_t c = (meta[0] >> 16) | (meta[NR - 1] & 0xFFFF0000u);
+    int x = (int)c;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    ex2 = (uint32_t)x - c;
+    tot2 = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  }
 #pragma unroll
   for (int q = 0; q < NR; q++) {
     const int cnt = (int)(meta[q] >> 16);
     // exclusive prefix sum of cnt over the wave: six DPP steps (row shifts, then the row broadcasts).  (A ballot +
     // mbcnt count of the single-token objects plus a uniform loop over the multi-token ones cost 4 us more per launch.)
     int off, total;
-    {
+    if (NR == 2) {
+      off = (int)(q == 0 ? (ex2 & 0xFFFFu) : (ex2 >> 16));
+      total = (int)(q == 0 ? (tot2 & 0xFFFFu) : (tot2 >> 16));
+    } else {
       int x = cnt;
       x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
       x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
