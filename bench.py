@@ -221,20 +221,32 @@ def main() -> None:
 
     accs = [b.summary_tensor() for b in batches]  # f64 accumulators in HBM, added to by the step kernels when an episode ends
 
+    # The only collective of the path: < 1 KB, no host round trip, and no group waits for it: each group
+    # hands its accumulator over on its own stream (copy + clear, in order with its steps), a side stream sums the
+    # copies and runs the all-reduce.  (Joining the group streams on one stream instead drains the pipeline of launches
+    # every time: 0.0509 against 0.0489 ms/step with a reduction every 128 steps.)
+    side = torch.cuda.Stream(device=dev)
+    stage = torch.zeros((len(accs), accs[0].numel()), dtype=accs[0].dtype, device=dev)
+    stage_free = torch.cuda.Event()  # the previous reduction has read `stage`
+    stage_free.record(side)
+
     def reduce_summary():
-        # the only collective of the path: < 1 KB, on the stream, no host round trip
-        cur = torch.cuda.current_stream(dev)
-        for st in streams:
-            cur.wait_stream(st)
-        s = accs[0].clone()
-        accs[0].zero_()
-        for acc in accs[1:]:
-            s += acc
-            acc.zero_()
-        for st in streams:
-            st.wait_stream(cur)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        summary.add_(s)
+        handed = []
+        for q, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                st.wait_event(stage_free)
+                stage[q].copy_(accs[q])
+                accs[q].zero_()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                handed.append(ev)
+        with torch.cuda.stream(side):
+            for ev in handed:
+                side.wait_event(ev)
+            s = stage.sum(0)
+            stage_free.record(side)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM)
+            summary.add_(s)
 
     def run(k: int, base: int, bs=None, tbs=None, sts=None):
         bs, tbs, sts = bs or batches, tbs or tables, sts or streams
