@@ -22,15 +22,20 @@ the headline).
 Environments shard across ranks as independent instances (no data-path collective: "scaling": "weak"); the only
 collective is the RCCL all-reduce of the finished-episode summary vector every 128 steps.
 
-Prints ONE JSON line on rank 0.  `roofline`: algorithmic bytes per launch (1035 B per agent-step, SURVEY §8d:
-610 B boundary + ~425 B state; one launch = one step of one group = the fused kernel mg_step_fused*_kernel over E/G
-environments) / mean kernel duration measured with HIP events on the launch's own stream over the timed steps (every
-8th step of every group is bracketed: the event pair is not free).  G such launches are in flight at any time (one per
-stream, back to back), so the rate the GPU sustains is `achieved` = `concurrency` x bytes per launch / mean launch
-duration; `per_launch_achieved` is the one-launch figure the formula of SURVEY §8d gives without the factor.
-`traffic` is the PMC-measured HBM bytes per launch from profiles/ (see DESIGN.md), null when not collected.
-`cpu_baseline`: the reference's own compiled core (oracle/_ref, kind "reference") or the oracle port, stepped on
-the host cores over a bounded sample of the same workload, rank 0 / N=1 only.
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes of one step of all the rank's environments
+(1035 B per agent-step, SURVEY §8d: 610 B boundary + ~425 B state; x E x A) / the WALL-CLOCK time per step of the timed
+region, so `frac` == 101.7 MB / ms_per_step / 8 TB/s.  Beside it, `per_launch`: the same bytes for one launch (one
+group's step = the fused kernel mg_step_fused*_kernel over E/G environments) / the mean duration of that launch
+measured with HIP events on the launch's own stream (every 8th step of every group is bracketed: the event pair is not
+free) -- never multiplied by the number of launches in flight.  `obs_kernel` (BASELINE's second metric, SURVEY §8d
+metric 2) is measured after the timed region on a handle of the same environments that runs the step as three
+launches, with events around the observation kernel `mg_obs_kernel` alone: 970 algorithmic bytes per agent-step (600
+written + ~370 read) / its mean duration.  `traffic` is the PMC-measured HBM bytes per launch from profiles/ (see
+DESIGN.md), null when not collected for this launch shape.
+`cpu_baseline`: the reference's own compiled core (oracle/_ref, kind "reference") or the oracle port inside a
+multiprocess vecenv of pufferlib's design (oracle/cpu_vecenv.py: one worker per core, environments stepped serially per
+worker, shared-memory buffers, busy-polled semaphores), on a bounded sample of the same workload, rank 0 / N=1 only;
+`upper_bound_no_ipc` beside it is the same core in independent processes with no vecenv at all.
 """
 
 from __future__ import annotations
@@ -108,6 +113,33 @@ def _cpu_worker(args):
     return done * n_envs * AGENTS, dt
 
 
+def _cpu_vecenv_leg(kind: str, cores: int, n_envs: int, budget_s: float):
+    """The named baseline: all environments behind ONE synchronous vecenv (send actions -> every worker steps its
+    environments -> recv), shared memory + semaphores (oracle/cpu_vecenv.py)."""
+    from metta_amd.builder import make_arena
+    from oracle.cpu_vecenv import CpuVecEnv
+
+    pool = _load_pool()
+    T = make_arena(AGENTS).game.obs.num_tokens
+    vec = CpuVecEnv(kind, lambda: make_arena(AGENTS), pool, cores, n_envs, AGENTS, T, seed=0)
+    try:
+        rs = np.random.RandomState(999)
+        acts = rs.randint(0, 5, size=(256, cores * n_envs * AGENTS)).astype(np.int32)
+        for t in range(20):  # warm-up (first touches of the shared pages)
+            vec.send(acts[t % 256])
+            vec.recv()
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < budget_s:
+            vec.send(acts[done % 256])
+            vec.recv()
+            done += 1
+        dt = time.perf_counter() - t0
+    finally:
+        vec.close()
+    return done * cores * n_envs * AGENTS / dt, done
+
+
 def cpu_baseline(budget_s: float = 10.0) -> dict:
     import multiprocessing as mp
 
@@ -123,18 +155,28 @@ def cpu_baseline(budget_s: float = 10.0) -> dict:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")), 16))
     n_envs, n_steps = 8, 100000
+    # the driver busy-polls the semaphores like the workers do (vector.py:415-455): it gets a core of its own, or a
+    # descheduled worker holds every step back (8 workers on 8 cores: half the rate of 7 + driver)
+    workers = max(1, cores - 1)
+    vec_rate, vec_steps = _cpu_vecenv_leg(kind, workers, n_envs, budget_s)
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(kind, w, n_envs, n_steps, budget_s) for w in range(cores)])
+        res = pool.map(_cpu_worker, [(kind, w, n_envs, n_steps, budget_s * 0.6) for w in range(cores)])
     rate = sum(n / dt for n, dt in res)
+    core = "reference C++ core compiled from /root/reference" if kind == "reference" else "oracle port"
     return {
-        "value": rate,
+        "value": vec_rate,
         "unit": "agent-steps/s",
         "cores": cores,
         "kind": kind,
-        "sample": f"{cores} independent processes x {n_envs} arena-24 envs stepped serially for ~{budget_s:.0f} s each, "
-        "no vecenv IPC (no shared-memory buffers, no semaphores: an upper bound for the reference's multiprocess CPU vecenv); "
-        f"same config/maps/action distribution; {'reference C++ core compiled from /root/reference' if kind == 'reference' else 'oracle port'}",
+        "sample": f"multiprocess vecenv of pufferlib's design (vector.py:185-511 restated in oracle/cpu_vecenv.py): {workers} worker "
+        f"processes (+ the busy-polling driver = {cores} cores) x {n_envs} arena-24 envs stepped serially per worker, zero-copy shared-memory buffers, busy-polled semaphores, "
+        f"synchronous send/recv over all {workers * n_envs} envs for ~{budget_s:.0f} s ({vec_steps} vecenv steps); "
+        f"same config/maps/action distribution; {core}",
+        "upper_bound_no_ipc": {
+            "value": rate,
+            "sample": f"{cores} independent processes x {n_envs} envs stepped serially for ~{budget_s * 0.6:.0f} s each, no vecenv at all",
+        },
     }
 
 
@@ -148,6 +190,7 @@ def main() -> None:
     ap.add_argument("--groups", type=int, default=4, help="independent environment groups, one HIP stream each (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the one-handle comparison run (profiling passes: one launch shape only)")
+    ap.add_argument("--no-obs-pass", action="store_true", help="skip the observation-kernel pass (metric 2) after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL summary all-reduce even with one rank (rehearsal)")
     args = ap.parse_args()
@@ -248,18 +291,21 @@ def main() -> None:
             dist.all_reduce(s, op=dist.ReduceOp.SUM)
             summary.add_(s)
 
-    def run(k: int, base: int, bs=None, tbs=None, sts=None):
-        bs, tbs, sts = bs or batches, tbs or tables, sts or streams
-        # (tensors validated here once; the loop hands the library raw pointers and stream handles)
+    def make_stepper(bs, tbs, sts):
+        """Everything the launch loop needs, built ONCE: the tensors are validated here, the loop hands the library raw
+        pointers and stream handles (one library call per step)."""
         assert all(tb.dtype == torch.int32 and tb.is_contiguous() and tb.shape[1] == b.actions.numel() for b, tb in zip(bs, tbs))
         ptrs = [[tb[r].data_ptr() for r in range(64)] for tb in tbs]
-        step = MettaGridBatch.group_stepper(bs, ptrs, [st.cuda_stream for st in sts])  # one library call per step
+        return MettaGridBatch.group_stepper(bs, ptrs, [st.cuda_stream for st in sts])
+
+    def run(step, k: int, base: int, reduce: bool = True):
         for t in range(k):
             step((base + t) % 64)
-            if use_dist and (base + t) % 128 == 127:
+            if reduce and use_dist and (base + t) % 128 == 127:
                 reduce_summary()
 
-    run(args.warmup, 0)
+    stepper = make_stepper(batches, tables, streams)
+    run(stepper, args.warmup, 0)
     if use_dist:
         reduce_summary()  # communicator set-up and first-use costs stay out of the timed region
     sync_all()
@@ -270,8 +316,9 @@ def main() -> None:
     # HIP events around every 8th step of the timed region: an event pair per step costs ~7 % of the step it times
     for b in batches:
         b.set_profiling(True, stride=PROFILE_STRIDE)
+    sync_all()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(stepper, args.steps, args.warmup)
     sync_all()
     dt = time.perf_counter() - t0
     kernel_ms = np.concatenate([b.profile_read(4096) for b in batches])
@@ -279,15 +326,6 @@ def main() -> None:
         b.set_profiling(False)
     step_path = batches[0].step_path()
     fused = "fused" in step_path
-    obs_ms = np.zeros(0, np.float32)
-    if not fused and G == 1:
-        # after the timed region: a short pass with events around the observation kernel alone (SURVEY 8d metric 2)
-        batches[0].set_profiling(2)
-        n_obs = min(args.steps, 100)
-        run(n_obs, args.warmup + args.steps)
-        sync_all()
-        obs_ms = batches[0].profile_read(4096)
-        batches[0].set_profiling(False)
     for b in batches:
         b.check_errors()  # an environment that left reference parity would void the measurement
     for b in batches:
@@ -298,25 +336,66 @@ def main() -> None:
         # the same workload through one handle on one stream (what --groups 1 reports as the headline)
         one = make_batches(1)
         cur = [torch.cuda.current_stream(dev)]
-        k1 = min(args.steps, 200)
-        run(min(args.warmup, 30), 0, one, [table], cur)
+        k1 = min(max(args.steps, 100), 200)
+        step1 = make_stepper(one, [table], cur)
+        run(step1, min(args.warmup, 30), 0, reduce=False)
         torch.cuda.synchronize(dev)
         one[0].set_profiling(True, stride=PROFILE_STRIDE)
         t1 = time.perf_counter()
-        run(k1, args.warmup, one, [table], cur)
+        run(step1, k1, args.warmup, reduce=False)
         torch.cuda.synchronize(dev)
         d1 = time.perf_counter() - t1
         km = one[0].profile_read(4096)
         one[0].check_errors()
+        p1 = one[0].step_path()
         one[0].close()
         single = {
             "steps": k1,
             "ms_per_step": d1 / k1 * 1e3,
             "value": E * A * k1 / d1,
+            "kernel": p1,
             "kernel_ms_mean": float(km.mean()) if len(km) else None,
-            "achieved": ALGO_BYTES_PER_AGENT_STEP * E * A / (float(km.mean()) * 1e-3) / 1e9 if len(km) else None,
-            "frac": ALGO_BYTES_PER_AGENT_STEP * E * A / (float(km.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS if len(km) else None,
+            "achieved": ALGO_BYTES_PER_AGENT_STEP * E * A / (d1 / k1) / 1e9,
+            "frac": ALGO_BYTES_PER_AGENT_STEP * E * A / (d1 / k1) / 1e9 / HBM_PEAK_GBS,
         }
+
+    obs_kernel = None
+    if rank == 0 and not args.no_obs_pass:
+        # BASELINE's second metric (SURVEY 8d metric 2): the observation kernel alone.  The fused step has no kernel
+        # boundary around its encode, so the same environments are stepped by a handle that runs the step as three
+        # launches (MG_NO_FUSED is read when the pool is set), with HIP events around mg_obs_kernel only.
+        os.environ["MG_NO_FUSED"] = "1"
+        try:
+            three = make_batches(1)
+        finally:
+            del os.environ["MG_NO_FUSED"]
+        cur = [torch.cuda.current_stream(dev)]
+        step3 = make_stepper(three, [table], cur)
+        run(step3, 20, 0, reduce=False)
+        torch.cuda.synchronize(dev)
+        three[0].set_profiling(2)
+        n_obs = 100
+        run(step3, n_obs, 20, reduce=False)
+        torch.cuda.synchronize(dev)
+        obs_ms = three[0].profile_read(4096)
+        three[0].set_profiling(False)
+        three[0].check_errors()
+        p3 = three[0].step_path()
+        three[0].close()
+        if len(obs_ms):
+            obs_bytes = OBS_BYTES_PER_AGENT_STEP * E * A
+            obs_s = float(obs_ms.mean()) * 1e-3
+            obs_kernel = {
+                "kernel": "mg_obs_kernel (the observation kernel of the three-launch step: " + p3 + ")",
+                "ms_mean": float(obs_ms.mean()),
+                "ms_min": float(obs_ms.min()),
+                "samples": int(len(obs_ms)),
+                "envs_per_launch": E,
+                "algorithmic_bytes_per_launch": obs_bytes,
+                "achieved": obs_bytes / obs_s / 1e9,
+                "unit": "GB/s",
+                "frac": obs_bytes / obs_s / 1e9 / HBM_PEAK_GBS,
+            }
 
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -326,10 +405,12 @@ def main() -> None:
     if rank == 0:
         agent_steps = float(world) * E * A * args.steps
         value = agent_steps / dt
+        step_s = dt / args.steps
+        algo_step = ALGO_BYTES_PER_AGENT_STEP * E * A  # one step of all the rank's environments
+        achieved = algo_step / step_s / 1e9  # from the wall clock of the timed region
         mean_kernel_s = float(kernel_ms.mean()) * 1e-3 if len(kernel_ms) else float("nan")
         algo_bytes = ALGO_BYTES_PER_AGENT_STEP * n * A  # one launch = one group's step
         per_launch = algo_bytes / mean_kernel_s / 1e9
-        achieved = per_launch * G  # G launches in flight, one per stream
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
@@ -370,24 +451,20 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "basis": "wall clock: algorithmic bytes of one step of all environments / (timed region / steps)",
+                "algorithmic_bytes_per_step": algo_step,
                 "kernel": step_path + (" (one launch per group and step: actions, assembler uses, observations, rewards)" if fused else ""),
-                "concurrency": G,
-                "envs_per_launch": n,
-                "per_launch_achieved": per_launch,
-                "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
-                "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
-                "kernel_ms_samples": int(len(kernel_ms)),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "obs_kernel": None
-                if fused
-                else {
-                    "ms_mean": float(obs_ms.mean()) if len(obs_ms) else None,
-                    "algorithmic_bytes_per_launch": OBS_BYTES_PER_AGENT_STEP * E * A,
-                    "achieved": OBS_BYTES_PER_AGENT_STEP * E * A / (float(obs_ms.mean()) * 1e-3) / 1e9 if len(obs_ms) else None,
-                    "frac": OBS_BYTES_PER_AGENT_STEP * E * A / (float(obs_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                    if len(obs_ms)
-                    else None,
+                "per_launch": {
+                    "envs_per_launch": n,
+                    "launches_in_flight": G,
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "kernel_ms_mean": float(kernel_ms.mean()) if len(kernel_ms) else None,
+                    "kernel_ms_min": float(kernel_ms.min()) if len(kernel_ms) else None,
+                    "kernel_ms_samples": int(len(kernel_ms)),
+                    "achieved": per_launch,
+                    "frac": per_launch / HBM_PEAK_GBS,
                 },
+                "obs_kernel": obs_kernel,
             },
             "single_stream": single,
             "cpu_baseline": cpu,

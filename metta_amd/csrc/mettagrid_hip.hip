@@ -163,6 +163,8 @@ struct mg_handle {
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
   bool fused_dcl = false, cells8 = false;
   bool no_modifiers = false;       // no group / chest has inventory-limit modifiers: the leaner build of the fused kernel
+  bool slot_has_modifiers = false; // sticky: a task with limit modifiers was written into a configuration slot (slots outlive the pool)
+  int* d_map_max_steps = nullptr;  // [P] per-map episode lengths (lives with the pool; allocated on first use)
   bool fused_o7 = false;           // ... the builds with a larger register budget (7 waves per SIMD; 6 with modifiers), see below
   bool big = false;                // map tile too large for LDS: grid (and, for obs/reset, agent records) in HBM
   int n_split = 1;                 // concurrent env groups per step (MG_SPLIT env var / mg_set_split)
@@ -565,6 +567,8 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   }
   for (void* p : h->map_allocs) (void)hipFree(p);
   h->map_allocs.clear();
+  h->d_map_max_steps = nullptr;  // (lived in map_allocs)
+  k.map_max_steps = nullptr;
   uint16_t* d_cells; int4* d_spawn; int4* d_asm; int* d_nasm; float* d_obj; DAsm* d_asms; int2* d_dims;
   if (dalloc(h, &d_dims, dims.size(), true)) return 1;
   HIPCHK(hipMemcpy(d_dims, dims.data(), dims.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -642,7 +646,9 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         k.map_cells8 = d8;
       }
       if (h->fused) {
-        h->no_modifiers = !mg_has_modifiers(c);
+        // (tasks written into configuration slots survive a new pool: a task with modifiers keeps the handle on the
+        // build that honours them, whatever the handle's own configuration says)
+        h->no_modifiers = !mg_has_modifiers(c) && !h->slot_has_modifiers;
         HIPCHK(mg_raise_lds_cap_fused((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod_o7((int)LDS_MAX));
@@ -750,6 +756,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     k.t_gstats = t_gstats; k.t_gtouched = t_gtouched;
   }
   k.map_max_steps = nullptr;  // (freed with the old pool)
+  h->d_map_max_steps = nullptr;
   if (!h->in_set_generated) h->generated = false;
   h->gen_ready = false;
   h->maps_set = true;
@@ -1104,7 +1111,11 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
     h->kt.fast = 0;
     h->fused = false;
   }
-  if (mg_has_modifiers(v)) h->no_modifiers = false;
+  if (mg_has_modifiers(v)) {
+    h->slot_has_modifiers = true;
+    h->no_modifiers = false;
+    h->fused_w1 = false;  // (the one-wave build exists without modifiers only)
+  }
   if (h->maps_set) {
     std::vector<int> maps;
     for (size_t m = 0; m < h->host_map_cfg.size(); m++)
@@ -1137,17 +1148,17 @@ int mg_set_map_max_steps(mg_handle* h, const int32_t* max_steps) {
   if (!h) return fail("mg_set_map_max_steps: NULL handle");
   if (!h->maps_set) return fail("mg_set_map_max_steps: call mg_set_maps first");
   HIPCHK(hipSetDevice(h->device));
-  HIPCHK(hipDeviceSynchronize());
   if (!max_steps) {
-    h->k.map_max_steps = nullptr;
+    h->k.map_max_steps = nullptr;  // (kernel arguments are captured per launch: steps already queued keep theirs)
     return 0;
   }
   for (int m = 0; m < h->k.P; m++)
     if (max_steps[m] < 0) return fail("mg_set_map_max_steps: negative episode length");
-  int* d = nullptr;
-  if (dalloc(h, &d, (size_t)h->k.P, true)) return 1;
-  HIPCHK(hipMemcpy(d, max_steps, (size_t)h->k.P * 4, hipMemcpyHostToDevice));
-  h->k.map_max_steps = d;
+  // one [P] array per pool, allocated on first use and reused by later calls (it lives and dies with the pool)
+  if (!h->d_map_max_steps && dalloc(h, &h->d_map_max_steps, (size_t)h->k.P, true)) return 1;
+  HIPCHK(hipDeviceSynchronize());  // steps in flight read the array
+  HIPCHK(hipMemcpy(h->d_map_max_steps, max_steps, (size_t)h->k.P * 4, hipMemcpyHostToDevice));
+  h->k.map_max_steps = h->d_map_max_steps;
   return 0;
 }
 

@@ -589,6 +589,11 @@ class AsyncDeviceVecEnv:
         k = self._next
         st = self._streams[k]
         st.wait_stream(torch.cuda.current_stream(self.groups[k].batch.device))  # the actions were produced there
+        if isinstance(actions, torch.Tensor) and actions.is_cuda:
+            # mg_step_actions reads the tensor in place on the group's stream; the caching allocator knows only the
+            # stream the tensor was allocated on, and would hand its block to the next allocation there as soon as
+            # the caller drops it (rollout_phase does, one iteration later) -- while the step may still be reading.
+            actions.record_stream(st)
         with torch.cuda.stream(st):
             self.groups[k].send(actions)
         self._next = (k + 1) % len(self.groups)
