@@ -54,50 +54,26 @@
 #define mg_fused_lds_bytes mg_fused_lds_bytes_nomod
 #define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod
 #endif
+#ifdef MG_FUSED_OCC_OVERRIDE  // (experiments: tools/fvariant.sh)
+#undef MG_FUSED_OCC
+#define MG_FUSED_OCC MG_FUSED_OCC_OVERRIDE
+#endif
 #ifndef MG_FUSED_THREADS
 #define MG_FUSED_THREADS 128
 #endif
-#define MG_FUSED_SLOTS 4  // assembler uses resolved concurrently (scratch slots of 96 ints)
-
-template <bool FILL>
-__host__ __device__ inline size_t mg_carve_fused(unsigned char* base, Lds* l, int A, int SG, int ROWB, int nwaves, int dcw,
-                                                 int NOBJ, int HEAP, int NP) {
-  size_t o = 0;
-  auto take = [&](size_t bytes) {
-    size_t at = o;
-    o = mg_align16(o + bytes);
-    return at;
-  };
-  size_t dco = take((size_t)dcw * 4);
-  size_t ag = take((size_t)A * sizeof(DAgent));
-  // row buffers (encode) <- aliases -> pending assembler uses (P1-P2)
-  size_t rows_b = (size_t)ROWB * nwaves;
-  if (rows_b < (size_t)A * 32) rows_b = (size_t)A * 32;
-  size_t rows = take(rows_b);
-  // token lists + per-object counts (P3) <- aliases -> use scratch (P2) <- aliases -> next MT19937 block (P0-P1)
-  size_t oc_b = mg_align16((size_t)(NOBJ + 1) * 4), hp_b = mg_align16((size_t)HEAP * 2);
-  size_t u_b = oc_b + hp_b;
-  if (u_b < (size_t)MG_FUSED_SLOTS * 96 * 4) u_b = (size_t)MG_FUSED_SLOTS * 96 * 4;
-  if (u_b < 624 * 4) u_b = 624 * 4;
-  size_t u = take(u_b);
-  const int WS = NP <= 128 ? 128 : ((NP + 63) & ~63);  // (two full rounds: the encoder reads them without a bounds test)
-  size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP);
-  size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16);
-  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A);
-  size_t fl = take(32), su = take((size_t)A);
-  if (FILL) {
-    l->dc = (int*)(base + dco);
-    l->grid = nullptr; l->ag = (DAgent*)(base + ag); l->ch = l->ag + A;
-    l->exec = (int*)(base + ex); l->tok_att = (int*)(base + ta); l->tokacc = (float*)(base + tk);
-    l->rows = (uint8_t*)(base + rows); l->pend = base + rows;
-    l->ocnt = (uint32_t*)(base + u) + 1; l->heap = (uint16_t*)(base + u + oc_b); l->pat = nullptr;
-    l->tmp = (int*)(base + u); l->mtnext = (uint32_t*)(base + u);
-    l->wscr = base + ws; l->ipat = base + ip; l->WS = WS;
-    l->gd = (int*)(base + gd); l->dirty_amt = (uint32_t*)(base + da); l->dirty_misc = (uint32_t*)(base + dm);
-    l->order = (uint16_t*)(base + ord); l->flags = (int*)(base + fl); l->succ = base + su;
-    l->gsetv = nullptr; l->gsetm = nullptr; l->win = nullptr;
-  }
-  return o;
+// The Lds pointers of the fused kernel from the layout in the kernel arguments (`smem` = the workgroup's dynamic LDS).
+__device__ __forceinline__ void mg_fused_lds(Lds& l, const KArgs& a, unsigned char* smem) {
+  const FusedLds& f = a.fl;
+  l.dc = (int*)(smem + f.dc);
+  l.grid = nullptr; l.ag = (DAgent*)(smem + f.ag); l.ch = l.ag + a.A;
+  l.exec = (int*)(smem + f.ex); l.tok_att = (int*)(smem + f.ta); l.tokacc = (float*)(smem + f.tk);
+  l.rows = (uint8_t*)(smem + f.rows); l.pend = smem + f.rows;
+  l.ocnt = (uint32_t*)(smem + f.u) + 1; l.heap = (uint16_t*)(smem + f.heap); l.pat = nullptr;
+  l.tmp = (int*)(smem + f.u); l.mtnext = (uint32_t*)(smem + f.u);
+  l.wscr = smem + f.ws; l.ipat = smem + f.ip; l.WS = f.WS;
+  l.gd = (int*)(smem + f.gd); l.dirty_amt = (uint32_t*)(smem + f.da); l.dirty_misc = (uint32_t*)(smem + f.dm);
+  l.order = (uint16_t*)(smem + f.ord); l.flags = (int*)(smem + f.fl); l.succ = smem + f.su;
+  l.gsetv = nullptr; l.gsetm = nullptr; l.win = nullptr;
 }
 
 // ---- P1: the action phase of mg_act_fast_kernel on LDS-staged state (wave 0, lane = agent) ---------------------------
@@ -212,7 +188,7 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
     tr = r + dy;
     tc = c + dx;
     inb = tr >= 0 && tc >= 0 && tr < H && tc < W;
-    if (inb) scell = (uint16_t)l.gmap[tr * W + tc];  // the static layer of the map (HBM pool, L2)
+    if (inb) scell = (uint16_t)l.gmap[tr * (W + a.PADC) + tc];  // the static layer of the map (HBM pool, L2; padded rows)
   }
   const CellCodec cc{a.NW, A, a.NAmax};
   const int skind = cc.kind(scell);
@@ -496,20 +472,24 @@ __device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& 
   }
 }
 
-// Fresh copies of the kernel arguments and the LDS carve for one phase, derived from an opaque kernarg pointer: the
-// values of the previous phase cannot be kept alive across the phase boundary (they would be spilled there: the phases
-// together need several times the registers any one of them does).
-template <bool DCL>
-__device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id,
-                                               int max_steps, int cfg_off) {
+// Fresh copies of the kernel arguments for one phase, read through an opaque kernarg pointer: the values of the
+// previous phase cannot be kept alive across the phase boundary (they would be spilled there: the phases together need
+// several times the scalar registers any one of them does, and a spilled scalar is a v_writelane / v_readlane pair on
+// the VECTOR unit -- at the start of round 3 more than half of the stage phase's vector instructions).  The compiler
+// loads only the fields a phase touches.
+__device__ __forceinline__ void mg_fused_kargs(KArgs& a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __attribute__((address_space(4))) KArgs* ka =
       (const __attribute__((address_space(4))) KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ka));
   a = *ka;
 #endif
-  mg_carve_fused<true>(smem, &l, a.A, a.SG, a.ROWB, MG_FUSED_THREADS >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
-                       a.NWINCELLS);
+}
+template <bool DCL>
+__device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* smem, int H, int W, uint32_t map_id,
+                                               int max_steps, int cfg_off) {
+  mg_fused_kargs(a);
+  mg_fused_lds(l, a, smem);
   const int e = blockIdx.x + a.env_base;
   l.gmap = a.map_cells8 + (size_t)map_id * a.HW8;
   l.as = a.asms + (size_t)e * a.NAmax;                             // used in place (HBM)
@@ -532,39 +512,58 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   DEnv env;
   int H, W, act = 0, NW_, actor = 0, max_steps, cfg_off;
   uint32_t mt_raw = 0;
+  uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1;
+  bool do_reset, slots;
 
-  // ---- P0: stage -----------------------------------------------------------------------------------------------
-  {
-    KArgs a = a0;
+  // ---- P0: stage.  In blocks that each read their own few kernel arguments (see mg_fused_kargs) --------------------
+  {  // P0a: the loads that depend on nothing but the environment's index, issued before the env words are waited for
+    KArgs a;
+    mg_fused_kargs(a);
     const int e = blockIdx.x + a.env_base;
-    Lds l;
-    const int NP = a.NWINCELLS;
-    mg_carve_fused<true>(smem, &l, a.A, a.SG, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP, NP);
     MG_STAMP(0);
-    // Everything that depends on nothing but e is requested before the env words are waited for.  A restart rewrites
-    // the records, so that rare case loads them again.
     const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
     const int n1 = a.A * (int)(sizeof(DAgent) / 16);
-    const bool two_pass = n1 <= 2 * nt;  // the usual shapes: at most two record chunks per thread
-    uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1;
-    if (two_pass) {
+    if (n1 <= 2 * nt) {  // the usual shapes: at most two record chunks per thread (a restart loads them again)
       if (tid < n1) v1 = s1[tid];
       if (tid + nt < n1) v2 = s1[tid + nt];
     }
-    const bool slots = a.map_cfg != nullptr;  // per-slot configurations: the stream is known only after the env words
+    slots = a.map_cfg != nullptr;  // per-slot configurations: the stream is known only after the env words
     if (DCL && !slots) {
       const uint4* __restrict__ s0 = (const uint4*)a.gdc;
-      uint4* d0 = (uint4*)l.dc;
+      uint4* d0 = (uint4*)(smem + a.fl.dc);
       for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
     }
+    if (lane < a.A) act = a.actions[(size_t)e * a.A + lane];  // (every wave: cheaper than choosing the acting wave first)
     env = a.env[e];
-    const bool do_reset = a.auto_reset && env.done;  // block-uniform
-    if (do_reset) mg_restart_env(a, e, env, tid, nt);
+    {  // the env words are the same in every lane: pin them to scalar registers.  Left to itself the allocator may
+       // carry them through the phases as vector registers and spill them there -- 16 bytes per LANE per spill.
+      env.step = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.step);
+      env.mt_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.mt_idx);
+      env.seed = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.seed);
+      env.map_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.map_id);
+      env.episodes = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.episodes);
+      env.early_reset = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.early_reset);
+      env.done = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.done);
+      env.error = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.error);
+    }
+    do_reset = a.auto_reset && env.done;  // block-uniform
+  }
+  if (do_reset) {  // P0b: episode restart (rare); rewrites the records
+    KArgs a;
+    mg_fused_kargs(a);
+    mg_restart_env(a, blockIdx.x + a.env_base, env, tid, nt);
+  }
+  bool need_twist;
+  {  // P0c: the map this environment plays, the window of MT19937 outputs this step may consume
+    KArgs a;
+    mg_fused_kargs(a);
+    const int e = blockIdx.x + a.env_base;
+    const int* gdc0 = a.gdc;
     mg_use_map(a, env.map_id);
-    cfg_off = (int)(a.gdc - a0.gdc);
+    cfg_off = (int)(a.gdc - gdc0);
     if (DCL && slots) {
       const uint4* __restrict__ s0 = (const uint4*)a.gdc;
-      uint4* d0 = (uint4*)l.dc;
+      uint4* d0 = (uint4*)(smem + a.fl.dc);
       for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];
     }
     H = a.H;
@@ -572,45 +571,61 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
     max_steps = a.max_steps;
     NW_ = a.NWIN < 64 ? a.NWIN : 64;
     const uint32_t* mt = a.mt + (size_t)e * 624;
-    const bool need_twist = (int)env.mt_idx + NW_ > 624;  // block-uniform
-    {  // (every wave: cheaper than choosing the acting wave before the loads)
-      if (lane < a.A) act = a.actions[(size_t)e * a.A + lane];
-      const int j = (int)env.mt_idx + lane;
-      if (lane < NW_ && j < 624) mt_raw = mt[j];
-    }
-    if (two_pass && !do_reset) {
-      if (tid < n1) ((uint4*)l.ag)[tid] = v1;
-      if (tid + nt < n1) ((uint4*)l.ag)[tid + nt] = v2;
+    need_twist = (int)env.mt_idx + NW_ > 624;  // block-uniform
+    const int j = (int)env.mt_idx + lane;
+    if (lane < NW_ && j < 624) mt_raw = mt[j];
+    const int n1 = a.A * (int)(sizeof(DAgent) / 16);
+    uint4* dag = (uint4*)(smem + a.fl.ag);
+    if (n1 <= 2 * nt && !do_reset) {
+      if (tid < n1) dag[tid] = v1;
+      if (tid + nt < n1) dag[tid + nt] = v2;
     } else {
-      for (int i = tid; i < n1; i += nt) ((uint4*)l.ag)[i] = s1[i];
+      const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
+      for (int i = tid; i < n1; i += nt) dag[i] = s1[i];
     }
-    for (int i = tid; i < a.SG; i += nt) l.gd[i] = 0;
+  }
+  {  // P0d: per-step LDS state
+    KArgs a;
+    mg_fused_kargs(a);
+    const int e = blockIdx.x + a.env_base;
+    const int NP = a.NWINCELLS;
+    int* gd = (int*)(smem + a.fl.gd);
+    uint32_t* da = (uint32_t*)(smem + a.fl.da);
+    uint32_t* dm = (uint32_t*)(smem + a.fl.dm);
+    for (int i = tid; i < a.SG; i += nt) gd[i] = 0;
     for (int i = tid; i < a.A; i += nt) {
-      l.dirty_amt[i] = 0;
-      l.dirty_misc[i] = 0;
+      da[i] = 0;
+      dm[i] = 0;
     }
-    for (int i = tid; i < ((nt >> 6) * 2 * l.WS) >> 2; i += nt) ((uint32_t*)l.wscr)[i] = 0;
+    uint32_t* wscr = (uint32_t*)(smem + a.fl.ws);
+    for (int i = tid; i < ((nt >> 6) * 2 * a.fl.WS) >> 2; i += nt) wscr[i] = 0;
     {  // window cell -> position in the pattern order
-      const int hr = a.gdc[DC_OBS_H] >> 1, wr = a.gdc[DC_OBS_W] >> 1, ow = a.gdc[DC_OBS_W], op = a.gdc[DC_OFF_PATTERN];
+      const int* gdc = a.gdc + cfg_off;
+      uint8_t* ipat = smem + a.fl.ip;
+      const int hr = gdc[DC_OBS_H] >> 1, wr = gdc[DC_OBS_W] >> 1, ow = gdc[DC_OBS_W], op = gdc[DC_OFF_PATTERN];
       for (int p = tid; p < NP; p += nt) {
-        const uint32_t packed = (uint32_t)a.gdc[op + p];
+        const uint32_t packed = (uint32_t)gdc[op + p];
         const int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
-        l.ipat[(dr + hr) * ow + dcc + wr] = (uint8_t)p;
+        ipat[(dr + hr) * ow + dcc + wr] = (uint8_t)p;
       }
     }
-    if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+    float* tokacc = (float*)(smem + a.fl.tk);
+    int* flags = (int*)(smem + a.fl.fl);
+    if (tid < 3) tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
     if (tid == 0) {
-      l.flags[3] = 0;
-      l.flags[2] = 0;
+      flags[3] = 0;
+      flags[2] = 0;
     }
     if (need_twist) {  // next MT19937 block (rare: once per 624 outputs of an environment)
-      for (int i = tid; i < 227; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
+      const uint32_t* mt = a.mt + (size_t)e * 624;
+      uint32_t* mtnext = (uint32_t*)(smem + a.fl.u);
+      for (int i = tid; i < 227; i += nt) mtnext[i] = mt_mix(mt[i], mt[i + 1], mt[i + 397]);
       __syncthreads();
-      for (int i = 227 + tid; i < 454; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+      for (int i = 227 + tid; i < 454; i += nt) mtnext[i] = mt_mix(mt[i], mt[i + 1], mtnext[i - 227]);
       __syncthreads();
-      for (int i = 454 + tid; i < 623; i += nt) l.mtnext[i] = mt_mix(mt[i], mt[i + 1], l.mtnext[i - 227]);
+      for (int i = 454 + tid; i < 623; i += nt) mtnext[i] = mt_mix(mt[i], mt[i + 1], mtnext[i - 227]);
       __syncthreads();
-      if (tid == 0) l.mtnext[623] = mt_mix(mt[623], l.mtnext[0], l.mtnext[396]);
+      if (tid == 0) mtnext[623] = mt_mix(mt[623], mtnext[0], mtnext[396]);
     }
     env.step += 1;
     actor = (MG_FUSED_THREADS == 64 || (a.diag & 4096)) ? 0 : (int)(blockIdx.x & 1u);  // spread the single-wave phases over the SIMDs
@@ -619,11 +634,12 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
 
   // ---- P1: actions (one wave) ------------------------------------------------------------------------------------
-  if (wave == actor) {
+  if (wave == actor) {  // (65536: timing / counter ablation, results wrong on purpose)
     KArgs a;
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
+    if (!(a.diag & 65536)) {  // (65536: timing / counter ablation, results wrong on purpose)
     uint32_t w = 0;
     {
       const int j = (int)env.mt_idx + lane;
@@ -642,6 +658,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       a.env[e] = env;  // (done / early_reset are updated by the closing phase)
       l.flags[3] = n_pending;
       if (env.error) atomicOr(&a.status[0], env.error);
+    }
     }
   }
   __syncthreads();
@@ -670,7 +687,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     __syncthreads();  // (the use scratch becomes the token lists)
-    mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
+    if (!(a.diag & 32)) mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
     __syncthreads();
     MG_STAMP(4);
   }
@@ -698,7 +715,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       }
     }
     __syncthreads();
-    mg_rewards_and_flags<true>(b, l, e, env, tid, nt);
+    if (!(b.diag & 64)) mg_rewards_and_flags<true>(b, l, e, env, tid, nt);
     __syncthreads();
     uint4* wd = (uint4*)(b.agents + (size_t)e * b.A);
     const uint4* ws = (const uint4*)l.ag;
@@ -712,8 +729,8 @@ void mg_launch_fused(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream
   else hipLaunchKernelGGL(mg_step_fused_kernel<false>, dim3(n), dim3(MG_FUSED_THREADS), lds, st, k);
 }
 size_t mg_fused_lds_bytes(const KArgs& k, bool dcl) {
-  return mg_carve_fused<false>(nullptr, nullptr, k.A, k.SG, k.ROWB, MG_FUSED_THREADS / 64, dcl ? k.dc_obs_words : 0, k.NOBJ,
-                               k.HEAP, k.NWINCELLS);
+  return mg_carve_fused(nullptr, k.A, k.SG, k.ROWB, MG_FUSED_THREADS / 64, dcl ? k.dc_obs_words : 0, k.NOBJ, k.HEAP,
+                        k.NWINCELLS);
 }
 hipError_t mg_raise_lds_cap_fused(int cap) {
   hipError_t e = hipFuncSetAttribute((const void*)mg_step_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
   uint8_t* bytes = smem;
   for (int i = tid; i < 256; i += nt) kcount[i] = 0;
   if (g.direct_slot >= 0) {  // a map uploaded by the host: only the derived pool entries are built here
-    const uint8_t* src = g.map_bytes + (size_t)m * g.HW8;
+    const uint8_t* src = g.map_bytes + (size_t)m * g.HWB;
     for (int i = tid; i < cells; i += nt) bytes[i] = src[i];
   } else {
   for (int i = tid; i < cells; i += nt) bytes[i] = (uint8_t)g.fill_code;
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
     CellCodec codec{g.NW, g.A, g.NAmax};
     uint16_t* cells16 = g.map_cells + (size_t)m * g.HW;
     uint8_t* cells8 = g.map_cells8 ? g.map_cells8 + (size_t)m * g.HW8 : nullptr;
-    uint8_t* raw = g.map_bytes + (size_t)m * g.HW8;
+    uint8_t* raw = g.map_bytes + (size_t)m * g.HWB;
+    const int Wp = W + g.PADC;  // rows of the byte copy carry PADC bytes of padding (left zero)
     for (int i = lo; i < hi; i++) {
       const int code = bytes[i];
       raw[i] = (uint8_t)code;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(MG_MAPGEN_THREADS) void mg_generate_maps_kernel(Map
         }
       }
       cells16[i] = v;
-      if (cells8) cells8[i] = (uint8_t)v;
+      if (cells8) cells8[(i / W) * Wp + i % W] = (uint8_t)v;
     }
   }
   __syncthreads();

@@ -159,6 +159,7 @@ struct mg_handle {
   std::vector<void*> map_allocs;
   size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0, lds_fused = 0, lds_fused_w1 = 0;
   bool fused_w1 = false;  // the one-wave-per-environment build of the fused kernel (few agents, no modifiers)
+  FusedLds fl2, fl1;      // LDS layouts of the two-wave builds / the one-wave build (handed over in the kernel arguments)
   bool dc_lds = false;
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
   bool fused_dcl = false, cells8 = false;
@@ -624,7 +625,14 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   // tile where every object code fits a byte.
   h->fused = false;
   k.map_cells8 = nullptr;
-  k.HW8 = (int)mg_align16((size_t)HWp);
+  // the byte copy of the pool (fused kernel): rows of W + PADC bytes, the PADC bytes after each row zero, so that a
+  // window cell beside the map reads "empty" without a bounds test (mg_window_lookup_direct)
+  k.PADC = c.obs_w >> 1;
+  {
+    size_t hw8 = 0;
+    for (int m = 0; m < num_maps; m++) hw8 = std::max(hw8, (size_t)heights[m] * (size_t)(widths[m] + k.PADC));
+    k.HW8 = (int)mg_align16(hw8);
+  }
   {
     const char* nf = getenv("MG_NO_FUSED");
     if (k.fast && !big && !(nf && nf[0] == '1')) {
@@ -639,7 +647,9 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
       if (h->fused) {
         std::vector<uint8_t> c8((size_t)num_maps * k.HW8, 0);
         for (int m = 0; m < num_maps; m++)
-          for (int i = 0; i < heights[m] * widths[m]; i++) c8[(size_t)m * k.HW8 + i] = (uint8_t)cells[(size_t)m * HWp + i];
+          for (int r = 0; r < heights[m]; r++)
+            for (int cc = 0; cc < widths[m]; cc++)
+              c8[(size_t)m * k.HW8 + (size_t)r * (widths[m] + k.PADC) + cc] = (uint8_t)cells[(size_t)m * HWp + (size_t)r * widths[m] + cc];
         uint8_t* d8 = nullptr;
         if (dalloc(h, &d8, c8.size(), true)) return 1;
         HIPCHK(hipMemcpy(d8, c8.data(), c8.size(), hipMemcpyHostToDevice));
@@ -657,6 +667,12 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         // A few agents per environment (navigation: 4): one wave does the whole step; a second one would repeat the
         // scalar work and wait through the action and use phases.  MG_FUSED_W1=0/1 overrides.
         h->lds_fused_w1 = mg_fused_lds_bytes_nomod_w1(k, h->fused_dcl);
+        {
+          const int dcw_f = h->fused_dcl ? k.dc_obs_words : 0;
+          const size_t b2 = mg_carve_fused(&h->fl2, k.A, k.SG, k.ROWB, 2, dcw_f, k.NOBJ, k.HEAP, k.NWINCELLS);
+          const size_t b1 = mg_carve_fused(&h->fl1, k.A, k.SG, k.ROWB, 1, dcw_f, k.NOBJ, k.HEAP, k.NWINCELLS);
+          if (b2 != h->lds_fused || b1 != h->lds_fused_w1) return fail("mg_set_maps: fused LDS layouts disagree (internal)");
+        }
         h->fused_w1 = h->no_modifiers && c.A <= 8 && h->lds_fused_w1 <= LDS_MAX;
         if (const char* w1 = getenv("MG_FUSED_W1")) h->fused_w1 = h->no_modifiers && w1[0] == '1' && h->lds_fused_w1 <= LDS_MAX;
         // 16 workgroups per CU (64 registers, some spilled) pay when the environments are exactly one round of them;
@@ -785,7 +801,7 @@ static int mg_mapgen_setup(mg_handle* h, int height, int width) {
   uint32_t *d_state, *d_inuse;
   uint8_t* d_bytes;
   if (dalloc(h, &d_list, P, true) || dalloc(h, &d_count, 1, true) || dalloc(h, &d_state, P, true) || dalloc(h, &d_inuse, P, true) ||
-      dalloc(h, &d_bytes, P * (size_t)k.HW8, true))
+      dalloc(h, &d_bytes, P * mg_align16((size_t)k.HW), true))
     return 1;
   MapGenArgs& g = h->gen;
   memset(&g, 0, sizeof(g));
@@ -800,7 +816,7 @@ static int mg_mapgen_setup(mg_handle* h, int height, int width) {
   g.map_chest = const_cast<int4*>(k.map_chest);
   g.map_nchest = const_cast<int*>(k.map_nchest);
   g.map_objcount = const_cast<float*>(k.map_objcount);
-  g.HW = k.HW; g.HW8 = k.HW8; g.A = k.A; g.NW = k.NW; g.NAmax = k.NAmax; g.NCmax = k.NCmax; g.n_cells = k.n_cells;
+  g.HW = k.HW; g.HW8 = k.HW8; g.HWB = (int)mg_align16((size_t)k.HW); g.PADC = k.PADC; g.A = k.A; g.NW = k.NW; g.NAmax = k.NAmax; g.NCmax = k.NCmax; g.n_cells = k.n_cells;
   g.slot_state = d_state; g.inuse = d_inuse; g.gen = 0;
   g.list = d_list; g.count = d_count; g.status = k.status;
   g.direct_slot = -1;
@@ -945,7 +961,7 @@ int mg_write_map_slot(mg_handle* h, int slot, const uint8_t* cells, void* stream
   if (!h->gen_ready && mg_mapgen_setup(h, height, width)) return 1;
   hipStream_t st = (hipStream_t)stream;
   MapGenArgs g = h->gen;
-  HIPCHK(hipMemcpyAsync(g.map_bytes + (size_t)slot * k.HW8, cells, (size_t)height * width, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(g.map_bytes + (size_t)slot * g.HWB, cells, (size_t)height * width, hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));  // (`cells` is the caller's)
   g.direct_slot = slot;
   HIPCHK(hipMemsetAsync(g.count, 0, sizeof(int), st));
@@ -968,7 +984,7 @@ int mg_get_map(mg_handle* h, int map_id, uint8_t* out, void* stream) {
   if (map_id < 0 || map_id >= h->k.P) return fail("mg_get_map: map id out of range");
   HIPCHK(hipSetDevice(h->device));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-  HIPCHK(hipMemcpy(out, h->gen.map_bytes + (size_t)map_id * h->k.HW8, (size_t)h->gen.height * h->gen.width, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, h->gen.map_bytes + (size_t)map_id * h->gen.HWB, (size_t)h->gen.height * h->gen.width, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1248,6 +1264,7 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
     const unsigned n = (unsigned)((long long)h->E * (gi + 1) / G) - (unsigned)kg.env_base;
     if (h->fused) {
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
+      kg.fl = (h->no_modifiers && h->fused_w1) ? h->fl1 : h->fl2;
       if (h->no_modifiers && h->fused_w1) mg_launch_fused_nomod_w1(kg, n, h->lds_fused_w1, h->fused_dcl, st);
       else if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);

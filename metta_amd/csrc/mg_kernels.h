@@ -22,6 +22,13 @@
   } while (0)
 #define MG_DC_LDS_MAX_WORDS 6144  // 24 KiB
 
+// LDS layout of the fused kernel (k_fused.hip), byte offsets from the start of the workgroup's dynamic LDS.  Computed
+// once on the host (mg_carve_fused) and handed over in the kernel arguments: a phase of the kernel reads the few
+// offsets it uses instead of redoing the whole carve (scalar instructions and live scalar registers, five times per step).
+struct FusedLds {
+  int dc, ag, rows, u, heap, ws, ip, ex, ta, tk, gd, da, dm, ord, fl, su, WS;
+};
+
 struct KArgs {
   const int* dc;
   const int* gdc;    // the whole config stream in HBM (dc may be re-pointed at an LDS copy of its prefix)
@@ -30,6 +37,8 @@ struct KArgs {
   const uint16_t* map_cells;  // [P][HW]
   const uint8_t* map_cells8;  // [P][HW8] the same codes as bytes when every object code fits one (fused kernel), else null
   int HW8;                    // byte stride of one map in map_cells8 (multiple of 16)
+  int PADC;                   // map_cells8 rows are W + PADC bytes long, the PADC bytes after each row zero (= obs_w / 2): a
+                              // window cell left or right of the map lands on padding and reads "empty" without a test
   const int4* map_spawn;      // [P][A]  (r, c, group, obj_id)
   const int4* map_asm;        // [P][NAmax] (r, c, cfg, obj_id)
   const int* map_nasm;        // [P]
@@ -104,6 +113,7 @@ struct KArgs {
   uint32_t* clip_mt;   // [E][624]
   uint2* clip_state;   // [E]
   uint32_t* clip_w;    // [E][NAmax]
+  FusedLds fl;         // fused kernel only: its LDS layout for this launch (two-wave or one-wave build, with / without the config prefix)
 };
 
 struct Lds {
@@ -140,6 +150,42 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+#define MG_FUSED_SLOTS 4  // fused kernel: assembler uses resolved concurrently (scratch slots of 96 ints)
+// The fused kernel's LDS plan; returns the bytes one workgroup needs.  About 10 KB per environment (arena): nothing
+// that other workgroups can share is copied into LDS (see k_fused.hip).
+__host__ __device__ inline size_t mg_carve_fused(FusedLds* f, int A, int SG, int ROWB, int nwaves, int dcw, int NOBJ, int HEAP,
+                                                 int NP) {
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = mg_align16(o + bytes);
+    return at;
+  };
+  size_t dco = take((size_t)dcw * 4);
+  size_t ag = take((size_t)A * sizeof(DAgent));
+  // row buffers (encode) <- aliases -> pending assembler uses (P1-P2)
+  size_t rows_b = (size_t)ROWB * nwaves;
+  if (rows_b < (size_t)A * 32) rows_b = (size_t)A * 32;
+  size_t rows = take(rows_b);
+  // token lists + per-object counts (P3) <- aliases -> use scratch (P2) <- aliases -> next MT19937 block (P0-P1)
+  size_t oc_b = mg_align16((size_t)(NOBJ + 1) * 4), hp_b = mg_align16((size_t)HEAP * 2);
+  size_t u_b = oc_b + hp_b;
+  if (u_b < (size_t)MG_FUSED_SLOTS * 96 * 4) u_b = (size_t)MG_FUSED_SLOTS * 96 * 4;
+  if (u_b < 624 * 4) u_b = 624 * 4;
+  size_t u = take(u_b);
+  const int WS = NP <= 128 ? 128 : ((NP + 63) & ~63);  // (two full rounds: the encoder reads them without a bounds test)
+  size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP);
+  size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16);
+  size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A);
+  size_t fl = take(32), su = take((size_t)A);
+  if (f) {
+    f->dc = (int)dco; f->ag = (int)ag; f->rows = (int)rows; f->u = (int)u; f->heap = (int)(u + oc_b);
+    f->ws = (int)ws; f->ip = (int)ip; f->ex = (int)ex; f->ta = (int)ta; f->tk = (int)tk; f->gd = (int)gd;
+    f->da = (int)da; f->dm = (int)dm; f->ord = (int)ord; f->fl = (int)fl; f->su = (int)su; f->WS = WS;
+  }
+  return o;
+}
 
 // Maps of one pool may differ in size (navigation suite): the kernel's copy of the arguments takes the dimensions of
 // the map its environment plays.
@@ -428,20 +474,19 @@ __device__ __forceinline__ uint32_t mg_byte_at(const MgByteMap& m, uint32_t off)
 // between uses).  `posj` = position of agent `lane` (r | c << 16), loaded once per wave.
 template <int NR>
 __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Lds& l, const EncCfg& ec, const DAgent* me,
-                                                        const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
-                                                        uint32_t& rc, const uint32_t posj, uint8_t* ws, const MgByteMap& gm) {
-  const int H = ec.H, W = ec.W, P = ec.P;
+                                                        const int (&dlt)[MG_MAX_ROUNDS], int lane, uint32_t (&meta)[NR],
+                                                        uint32_t& rc, const uint32_t posj, uint8_t* ws, const MgByteMap& gm,
+                                                        const int Wp) {
   rc = *(const uint32_t*)me;
   const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
+  // Rows of the byte map are Wp = W + PADC long with zero padding, and the buffer descriptor spans exactly the map's H
+  // rows: a window cell left / right of the map reads padding, one above / below it lies outside the descriptor's
+  // range (a negative offset is a huge unsigned one) and reads 0 -- "empty" either way, with no bounds test.  `dlt` is
+  // the lane's window offset dr * Wp + dc (an out-of-range constant for lanes past the pattern).
+  const int base = __mul24(ar, Wp) + ac;
   uint32_t cvs[NR];
 #pragma unroll
-  for (int q = 0; q < NR; q++) {
-    const int p = q * 64 + lane;
-    const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
-    const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W;
-    const uint32_t v = mg_byte_at(gm, (uint32_t)(__mul24(r, W) + c));  // (whatever it reads when !ok is masked)
-    cvs[q] = ok ? v : 0u;
-  }
+  for (int q = 0; q < NR; q++) cvs[q] = mg_byte_at(gm, (uint32_t)(base + dlt[q]));
   const int jr = (int)(posj & 0xFFFF) - ar, jc = (int)(posj >> 16) - ac;
   const bool inwin = lane < a.A && jr >= -ec.hr && jr <= ec.hr && jc >= -ec.wr && jc <= ec.wr;
   int pj = 0;
@@ -468,10 +513,45 @@ __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Ld
   }
 }
 
+// Up to four tokens of one object -- v = two dwords of (feature | value << 8) pairs -- as the row bytes
+// loc f v  loc f v ..., written with the widest stores that cover exactly 3 m bytes.  The row sits at any byte phase:
+// LDS stores of 2 to 12 bytes need no alignment on this hardware (tools/microbench/unaligned_lds.hip checks every
+// phase), and a token costs a fraction of the three byte stores it used to.  loc4 = the location byte, replicated.
+typedef uint16_t mg_u16_unaligned __attribute__((aligned(1)));
+typedef uint32_t mg_u32_unaligned __attribute__((aligned(1)));
+struct __attribute__((packed)) MgPack8 { uint32_t a, b; };
+struct __attribute__((packed)) MgPack12 { uint32_t a, b, c; };
+__device__ __forceinline__ void mg_put_tokens(uint8_t* __restrict__ dst, const uint2 v, const uint32_t loc4, const int m) {
+  const uint32_t d0 = (loc4 & 0xFF0000FFu) | ((v.x & 0xFFFFu) << 8);            // loc f0 v0 loc
+  const uint32_t d1 = (v.x >> 16) | (loc4 & 0x00FF0000u) | (v.y << 24);          // f1 v1 loc f2
+  const uint32_t d2 = ((v.y >> 8) & 0xFFu) | (loc4 & 0x0000FF00u) | (v.y & 0xFFFF0000u);  // v2 loc f3 v3
+#ifdef MG_NARROW_TOKENS  // (A/B switch: byte stores)
+  {
+    const uint32_t t[4] = {v.x & 0xFFFF, v.x >> 16, v.y & 0xFFFF, v.y >> 16};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < m) { dst[k * 3] = (uint8_t)loc4; dst[k * 3 + 1] = (uint8_t)t[k]; dst[k * 3 + 2] = (uint8_t)(t[k] >> 8); }
+    return;
+  }
+#endif
+  if (m == 1) {
+    *(mg_u16_unaligned*)dst = (uint16_t)d0;
+    dst[2] = (uint8_t)(d0 >> 16);
+  } else if (m == 2) {
+    *(mg_u32_unaligned*)dst = d0;
+    *(mg_u16_unaligned*)(dst + 4) = (uint16_t)d1;
+  } else if (m == 3) {
+    *(MgPack8*)dst = MgPack8{d0, d1};
+    dst[8] = (uint8_t)d2;
+  } else {
+    *(MgPack12*)dst = MgPack12{d0, d1, d2};
+  }
+}
+
 template <int NR, bool HOT = false>
 __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, const EncCfg& ec, const GlobalTok& gt,
                                       const DAgent* me, int action, uint8_t* __restrict__ row,
-                                      const uint32_t (&pk)[MG_MAX_ROUNDS], int lane, const uint32_t (&meta)[NR],
+                                      const uint32_t (&loc4)[MG_MAX_ROUNDS], int lane, const uint32_t (&meta)[NR],
                                       const uint32_t rc) {
   const int T = ec.T, hr = ec.hr, wr = ec.wr, H = ec.H, W = ec.W;
   const int ar = (int)(rc & 0xFFFF), ac = (int)(rc >> 16);
@@ -546,9 +626,13 @@ __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, con
     if (cnt > 0 && off < T && (HOT || !(a.diag & 128))) {
       // token lists start 8-byte aligned and are padded to x4 tokens: read 4 tokens per LDS access
       const uint2* __restrict__ src = (const uint2*)(l.heap + (meta[q] & 0xFFFF));
-      const uint8_t loc = (uint8_t)(pk[q] >> 16);
       const int n = min(cnt, T - off);
       uint8_t* __restrict__ dst = row + off * 3;
+#ifdef MG_PUT_TOKENS  // (A/B: wide unaligned stores, or MG_NARROW_TOKENS byte stores through the same helper)
+      mg_put_tokens(dst, src[0], loc4[q], n);  // (walls show one token, most objects at most four)
+      for (int k = 4; k < n; k += 4) mg_put_tokens(dst + k * 3, src[k >> 2], loc4[q], n - k);
+#else
+      const uint8_t loc = (uint8_t)loc4[q];
       uint2 v = src[0];
       {  // most objects (walls) have one token: it goes out without any further test
         const uint32_t t0 = v.x & 0xFFFF;
@@ -564,6 +648,7 @@ __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, con
           if (k + 3 < n) { dst[k * 3 + 9] = loc; dst[k * 3 + 10] = (uint8_t)t3; dst[k * 3 + 11] = (uint8_t)(t3 >> 8); }
         }
       }
+#endif
     }
     base += total;
   }
@@ -582,10 +667,20 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   const int row_bytes = a.T * 3;
   const EncCfg ec = mg_enc_cfg(a);
   const GlobalTok gt = mg_global_tok(a, step, lane);
-  uint32_t pk[MG_MAX_ROUNDS];
+  uint32_t pk[MG_MAX_ROUNDS], loc4[MG_MAX_ROUNDS];
+  int dlt[MG_MAX_ROUNDS];
+  const int Wp = ec.W + a.PADC;  // row stride of the padded byte map (DIRECT)
 #pragma unroll
-  for (int q = 0; q < MG_MAX_ROUNDS; q++)
-    pk[q] = (q < NR && (q * 64 + lane) < ec.P) ? (PAT ? l.pat[q * 64 + lane] : mg_pattern_entry(a.gdc, q * 64 + lane)) : 0u;
+  for (int q = 0; q < MG_MAX_ROUNDS; q++) {
+    const bool in_pat = q < NR && (q * 64 + lane) < ec.P;
+    pk[q] = in_pat ? (PAT ? l.pat[q * 64 + lane] : mg_pattern_entry(a.gdc, q * 64 + lane)) : 0u;
+#ifdef MG_PUT_TOKENS
+    loc4[q] = (pk[q] >> 16) * 0x01010101u;
+#else
+    loc4[q] = pk[q] >> 16;
+#endif
+    dlt[q] = in_pat ? __mul24((int)(pk[q] & 0xFF) - 8, Wp) + (int)((pk[q] >> 8) & 0xFF) - 8 : 0x40000000;
+  }
   // Rows whose length is 8 mod 16 (T = 200: 600 bytes) alternate between phase 0 and 8 in HBM.  A wave then takes
   // two consecutive agents: the even row keeps its last 8 bytes back, and they leave at the front of the odd row,
   // so that every store is a full aligned 16-byte chunk (8-byte partial stores of two waves into one chunk cost
@@ -598,7 +693,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   uint2 carry = make_uint2(0, 0);
   uint32_t posj = 0;
   if (DIRECT && lane < a.A) posj = *(const uint32_t*)&l.ag[lane];
-  const MgByteMap gm = mg_byte_map(DIRECT ? l.gmap : nullptr, DIRECT ? a.HW8 : 0);
+  const MgByteMap gm = mg_byte_map(DIRECT ? l.gmap : nullptr, DIRECT ? __mul24(ec.H, Wp) : 0);
   // per-agent offsets are carried along instead of multiplied out (v_mul_lo_u32 runs at quarter rate)
   uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
   const DAgent* me0 = l.ag + wave * group;
@@ -609,7 +704,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
 #pragma unroll
     for (int h = 0; h < group; h++) {
       if (DIRECT)
-        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS, gm);
+        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, dlt, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS, gm, Wp);
       else
         mg_window_lookup<NR, PAIRS, CT>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
     }
@@ -629,7 +724,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
       if (pairs && h == 1 && lane == 0) *(uint2*)rowbuf = carry;  // phase == 8 here
       __builtin_amdgcn_wave_barrier();
       const int act = exec ? exec[ai] : 0;
-      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, pk, lane, meta[h], rc[h]);
+      int attempted = mg_encode_agent<NR, PAIRS>(a, l, ec, gt, me0 + h, act, row, loc4, lane, meta[h], rc[h]);
       if (lane == 0) l.tok_att[ai] = attempted;
       __builtin_amdgcn_wave_barrier();
       if (write_global && !(a.diag & 1)) {

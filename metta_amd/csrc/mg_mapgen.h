@@ -18,15 +18,15 @@ struct MapGenArgs {
   const int* sym_count;
   // pool entries written
   uint16_t* map_cells;
-  uint8_t* map_cells8;  // or null
-  uint8_t* map_bytes;   // [P][HW8] the generated maps as cell codes (read back by mg_get_map)
+  uint8_t* map_cells8;  // or null; [P][HW8], rows of width + PADC bytes (the padding stays zero)
+  uint8_t* map_bytes;   // [P][HWB] the generated maps as cell codes (read back by mg_get_map)
   int4* map_spawn;
   int4* map_asm;
   int* map_nasm;
   int4* map_chest;
   int* map_nchest;
   float* map_objcount;
-  int HW, HW8, A, NW, NAmax, NCmax, n_cells;
+  int HW, HW8, HWB, PADC, A, NW, NAmax, NCmax, n_cells;
   // slot selection
   uint32_t* slot_state;   // [P] 1 = used by an episode since its last generation
   const uint32_t* inuse;  // [P] == gen where an environment is on the slot now
