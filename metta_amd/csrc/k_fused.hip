@@ -687,7 +687,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     __syncthreads();  // (the use scratch becomes the token lists)
-    if (!(a.diag & 32)) mg_build_tokens<uint8_t, false>(a, l, (int)env.map_id, env.step, tid, nt);
+    if (!(a.diag & 32)) mg_build_tokens_fused(a, l, (int)env.map_id, env.step, tid, nt);
     __syncthreads();
     MG_STAMP(4);
   }

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
     for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = ai_src[i];
   }
   __syncthreads();
+  if (a.build_templates && a.t_asm_tok) mg_build_asm_templates<uint16_t>(a, l, e, (int)env.map_id, tid, nt);  // (e = the map slot)
   mg_build_tokens(a, l, (int)env.map_id, 0, tid, nt);
   __syncthreads();
   mg_encode_all(a, l, e, 0, nullptr, true, tid, nt);

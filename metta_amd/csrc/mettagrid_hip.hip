@@ -723,7 +723,15 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (dalloc(h, &t_gtouched, P * k.GW, true)) return 1;
     // (the reset kernel's other outputs -- observations, flags, RNG -- land in throw-away buffers kept with the pool,
     // so that mg_refresh_maps can rebuild templates without allocating)
+    k.t_asm_tok = nullptr;
+    k.t_asm_n = nullptr;
+    k.build_templates = 0;
+    if (h->fused) {  // static token lists of the assemblers, per map (built by the template pass below)
+      if (dalloc(h, &k.t_asm_tok, P * (size_t)NAmax * 2 * (size_t)TSS, true)) return 1;
+      if (dalloc(h, &k.t_asm_n, P * (size_t)NAmax, true)) return 1;
+    }
     KArgs kt = k;
+    kt.build_templates = 1;
     kt.E = (int)P;
     uint32_t* d_seeds = nullptr;
     int* d_maps = nullptr;

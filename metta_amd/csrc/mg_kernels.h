@@ -113,6 +113,14 @@ struct KArgs {
   uint32_t* clip_mt;   // [E][624]
   uint2* clip_state;   // [E]
   uint32_t* clip_w;    // [E][NAmax]
+  // Static token lists of each map's assemblers (fused kernel): what a station shows while idle and while cooling
+  // down never changes during an episode except for the cooldown value, so the template build (reset kernel) keeps both
+  // lists per station and a step copies one instead of walking the configuration.  t_asm_n = tokens of the idle list
+  // (the cooling list has one more: cooldown_remaining first), 255 = not static (max_uses, clipped, a protocol that
+  // depends on the neighbours' vibes): built the long way every step.
+  uint16_t* t_asm_tok;  // [P][NAmax][2][TSS]
+  uint8_t* t_asm_n;     // [P][NAmax]
+  int build_templates;  // reset kernel: this launch builds the per-map templates (writes the two arrays above)
   FusedLds fl;         // fused kernel only: its LDS layout for this launch (two-wave or one-wave build, with / without the config prefix)
 };
 
@@ -364,6 +372,75 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
   if (PAT) {
     const int P = dc[DC_PATTERN_N];
     for (int p = tid; p < P; p += nt) l.pat[p] = mg_pattern_entry(a.gdc, p);
+  }
+}
+
+// The fused kernel's token lists: walls and agents as above; assemblers from the per-map static lists where they
+// apply (KArgs::t_asm_tok) -- a 16-byte record load, a list copy and the cooldown value instead of the walk through
+// the configuration stream (assembler.hpp:528-578), which was a tenth of the step's instructions.
+__device__ inline void mg_build_tokens_fused(const KArgs& a, const Lds& l, int map_id, uint32_t step, int tid, int nt) {
+  const int* dc = a.dc;
+  const CellCodec cc{a.NW, a.A, a.NAmax};
+  const int nasm = a.map_nasm[map_id];
+  const int first_asm = a.NW + a.A;
+  const uint32_t f_cd = (uint32_t)dc[DC_FID0 + MG_F_COOLDOWN] & 0xFFu;
+  for (int obj = tid; obj < a.NOBJ; obj += nt) {
+    const int ho = mg_heap_off(a, obj);
+    int n = 0;
+    bool done = obj >= first_asm + nasm;  // (unused assembler slots: no tokens)
+    if (!done && obj >= first_asm) {
+      const int idx = obj - first_asm;
+      const int ns = a.t_asm_n[(size_t)map_id * a.NAmax + idx];
+      const DAsm s = l.as[idx];
+      if (ns != 255 && s.clipped == 0) {
+        uint32_t remaining = s.cooldown_end <= step ? 0 : s.cooldown_end - step;
+        if (remaining > 255u) remaining = 255u;
+        const int variant = remaining > 0 ? 1 : 0;
+        n = ns + variant;
+        const uint2* __restrict__ src = (const uint2*)(a.t_asm_tok + (((size_t)map_id * a.NAmax + idx) * 2 + variant) * a.TSS);
+        uint2* dst = (uint2*)(l.heap + ho);
+        uint2 v = src[0];
+        if (variant) v.x = (v.x & 0xFFFF0000u) | f_cd | (remaining << 8);
+        dst[0] = v;
+        for (int k = 1; k * 4 < n; k++) dst[k] = src[k];
+        done = true;
+      }
+    }
+    if (!done) {
+      PairOut out{l.heap + ho, 0};
+      mg_object_tokens(dc, (const uint8_t*)nullptr, l.ag, l.as, l.ainfo, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, a.map_chest);
+      n = out.n;
+    }
+    l.ocnt[obj] = (uint32_t)ho | ((uint32_t)n << 16);
+  }
+  if (tid == 0) l.ocnt[-1] = 0;  // cell code 0 (empty) looks up "no tokens" without a branch
+}
+
+// Template build (reset kernel): the static lists of map slot `m`'s assemblers, see KArgs::t_asm_tok.
+template <class CT>
+__device__ inline void mg_build_asm_templates(const KArgs& a, const Lds& l, int m, int map_id, int tid, int nt) {
+  const int* dc = a.dc;
+  const CellCodec cc{a.NW, a.A, a.NAmax};
+  const int nasm = a.map_nasm[map_id];
+  for (int i = tid; i < a.NAmax; i += nt) {
+    uint16_t* dst = a.t_asm_tok + ((size_t)m * a.NAmax + i) * 2 * a.TSS;
+    for (int k = 0; k < 2 * a.TSS; k++) dst[k] = 0;
+    int n = 255;
+    if (i < nasm) {
+      const int* rec = asm_rec(dc, l.ainfo[i].z);
+      const bool is_static = rec[AR_MAX_USES] == 0 && l.as[i].clipped == 0 && (dc[DC_PROTO_OBS] == 0 || rec[AR_SIMPLE_PO] >= 0);
+      if (is_static) {
+        DAsm tmp = {0u, 0u, 0u, 0u};
+        const DAsm* fake = &tmp - i;  // (mg_object_tokens indexes the record array by the station's index)
+        PairOut idle{dst, 0};
+        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, 0u, cc.assembler(i), idle);
+        tmp.cooldown_end = 1u;  // step 0: one tick left -- the value is patched in every step
+        PairOut cooling{dst + a.TSS, 0};
+        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, 0u, cc.assembler(i), cooling);
+        n = (cooling.n == idle.n + 1 && idle.n < 255) ? idle.n : 255;
+      }
+    }
+    a.t_asm_n[(size_t)m * a.NAmax + i] = (uint8_t)n;
   }
 }
 
