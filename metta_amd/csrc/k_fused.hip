@@ -21,6 +21,15 @@
 // buffers (mode / pending uses / executed action) never leave LDS.
 #define MG_NO_CLIPPER  // (configurations with a Clipper take the general kernels)
 #include "mg_kernels.h"
+// Wave priority in the two serial phases (s_setprio): the workgroups that end a launch are those with assembler uses,
+// and in both phases one wave works while its partner waits at the barrier.  One launch over 4096 environments
+// 0.0605 -> 0.0570 ms; the four-stream form is indifferent (levels 1..3 tried, no difference between them).
+#ifndef MG_PRIO_USES
+#define MG_PRIO_USES 2
+#endif
+#ifndef MG_PRIO_ACT
+#define MG_PRIO_ACT 1
+#endif
 
 // Built twice: as is, and through k_fused_nomod.hip with MG_NO_MODIFIERS (configurations without inventory-limit
 // modifiers, e.g. arena and navigation: the use code then needs far fewer registers).
@@ -70,7 +79,7 @@ __device__ __forceinline__ void mg_fused_lds(Lds& l, const KArgs& a, unsigned ch
   l.rows = (uint8_t*)(smem + f.rows); l.pend = smem + f.rows;
   l.ocnt = (uint32_t*)(smem + f.u) + 1; l.heap = (uint16_t*)(smem + f.heap); l.pat = nullptr;
   l.tmp = (int*)(smem + f.u); l.mtnext = (uint32_t*)(smem + f.u);
-  l.wscr = smem + f.ws; l.ipat = smem + f.ip; l.WS = f.WS;
+  l.wscr = smem + f.ws; l.ipat = smem + f.ip; l.WS = f.WS;  // (ipat: re-pointed at the staged config by mg_fused_phase<true>)
   l.gd = (int*)(smem + f.gd); l.dirty_amt = (uint32_t*)(smem + f.da); l.dirty_misc = (uint32_t*)(smem + f.dm);
   l.order = (uint16_t*)(smem + f.ord); l.flags = (int*)(smem + f.fl); l.succ = smem + f.su;
   l.gsetv = nullptr; l.gsetm = nullptr; l.win = nullptr;
@@ -264,6 +273,15 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
     user = !(used_up || cooling);
   }
   unsigned long long umask = __ballot(user);
+  // A use that is alone in its step meets the inventories exactly as they were staged (nothing else on this path
+  // changes them), so whether the surrounding agents can pay the protocol's inputs (can_afford_protocol,
+  // assembler.hpp:124-137) is decided here, across the lanes; an unaffordable use has no effect but the failed move
+  // and never reaches the serial phase.  (Two thirds of the queued uses failed there under random actions.)
+#ifdef MG_NO_AFFORD_FILTER
+  const bool lone_use = false;
+#else
+  const bool lone_use = __popcll(umask) == 1;
+#endif
   int n_pending = 0;
   uint8_t* pend = l.pend;
   while (umask) {
@@ -298,6 +316,31 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
     int o9m = (dr + 1) * 3 + (dcl + 1);
     int om = o9m < 4 ? o9m : o9m - 1;
     int posidx = adj ? __popc(vmask8 & ((1u << om) - 1u)) : 0;
+    if (lone_use) {
+      const int cfg_b = __builtin_amdgcn_readlane(bump_cfg, best);
+      const uint32_t clipped_b = (uint32_t)__builtin_amdgcn_readlane((int)bump_as.clipped, best);
+      const uint32_t cd_end_b = (uint32_t)__builtin_amdgcn_readlane((int)bump_as.cooldown_end, best);
+      const int po = asm_rec(dc, cfg_b)[AR_SIMPLE_PO];
+      if (po >= 0 && clipped_b == 0 && cd_end_b <= env.step) {  // (partial usage while cooling: left to the serial phase)
+        const int oin = dc[po + PR_OFF_IN], n_in = L_n(dc, oin);
+        bool afford = true;
+        for (int i = 0; i < n_in; i++) {
+          int x = adj ? (int)rec->amt[KV_k(dc, oin, i)] : 0;
+          x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // wave sum: row shifts, then row broadcasts
+          x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+          x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+          x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+          x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+          x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+          const int total = __builtin_amdgcn_readlane(x, 63) & 0xFFFF;  // (the reference adds in uint16)
+          if (total < (KV_v(dc, oin, i) & 0xFFFF)) afford = false;
+        }
+        if (!afford) {
+          if (lane == best) user = false;  // counted as a failed move by the bookkeeping below
+          continue;
+        }
+      }
+    }
     const int start = __builtin_amdgcn_readlane(posidx, best);  // the actor is adjacent by construction
     int key = adj ? (posidx - start + np) % np : -1;
     uint8_t* rec8 = pend + (size_t)n_pending * 32;
@@ -449,12 +492,20 @@ __device__ __forceinline__ void mg_fused_token_stats(const KArgs& a, const Lds& 
     sd += att - wr;
     sf += a.T - wr;
   }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    sw += __shfl_xor(sw, off);
-    sd += __shfl_xor(sd, off);
-    sf += __shfl_xor(sf, off);
-  }
+  // wave sums on the vector unit's own cross-lane paths (DPP row shifts + row broadcasts; the total lands in lane 63) --
+  // a __shfl_xor butterfly is six dependent trips through the LDS crossbar per value
+  auto wave_sum = [](int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+  };
+  sw = wave_sum(sw);
+  sd = wave_sum(sd);
+  sf = wave_sum(sf);
   const float w0 = l.tokacc[0], d0 = l.tokacc[1], f0 = l.tokacc[2];
   const float lim = 16777216.0f;
   const bool exact = w0 + (float)sw < lim && d0 + (float)sd < lim && f0 + (float)sf < lim && sw < (1 << 23) &&
@@ -496,10 +547,20 @@ __device__ __forceinline__ void mg_fused_phase(KArgs& a, Lds& l, unsigned char* 
   l.ainfo = (int4*)(a.map_asm + (size_t)map_id * a.NAmax);         // read only
   a.gdc += cfg_off;  // per-slot configurations (0 without)
   a.dc = DCL ? l.dc : a.gdc;
+  if (DCL) l.ipat = (uint8_t*)(l.dc + l.dc[DC_OFF_IPAT]);
   a.H = H;
   a.W = W;
   a.max_steps = max_steps;
 }
+
+// Thread ids of one phase, derived afresh behind an opaque copy: shared across the phases, the allocator keeps values
+// derived from them (the zero-extended lane index of every 64-bit address) alive through the whole kernel and spills
+// them in the tight builds (8 waves per SIMD: 17 spilled vector registers, reloaded in every phase).
+#define MG_PHASE_IDS                         \
+  int tid = (int)threadIdx.x;                \
+  asm volatile("" : "+v"(tid));              \
+  const int lane = tid & 63, wave = tid >> 6; \
+  (void)lane; (void)wave;
 
 template <bool DCL>
 #ifndef MG_FUSED_OCC
@@ -507,8 +568,7 @@ template <bool DCL>
 #endif
 __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_kernel(KArgs a0) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, nt = MG_FUSED_THREADS;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int nt = MG_FUSED_THREADS;
   DEnv env;
   int H, W, act = 0, NW_, actor = 0, max_steps, cfg_off;
   uint32_t mt_raw = 0;
@@ -518,6 +578,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   // ---- P0: stage.  In blocks that each read their own few kernel arguments (see mg_fused_kargs) --------------------
   {  // P0a: the loads that depend on nothing but the environment's index, issued before the env words are waited for
     KArgs a;
+    MG_PHASE_IDS
     mg_fused_kargs(a);
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(0);
@@ -550,12 +611,14 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
   if (do_reset) {  // P0b: episode restart (rare); rewrites the records
     KArgs a;
+    MG_PHASE_IDS
     mg_fused_kargs(a);
     mg_restart_env(a, blockIdx.x + a.env_base, env, tid, nt);
   }
   bool need_twist;
   {  // P0c: the map this environment plays, the window of MT19937 outputs this step may consume
     KArgs a;
+    MG_PHASE_IDS
     mg_fused_kargs(a);
     const int e = blockIdx.x + a.env_base;
     const int* gdc0 = a.gdc;
@@ -586,6 +649,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
   {  // P0d: per-step LDS state
     KArgs a;
+    MG_PHASE_IDS
     mg_fused_kargs(a);
     const int e = blockIdx.x + a.env_base;
     const int NP = a.NWINCELLS;
@@ -599,14 +663,14 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
     }
     uint32_t* wscr = (uint32_t*)(smem + a.fl.ws);
     for (int i = tid; i < ((nt >> 6) * 2 * a.fl.WS) >> 2; i += nt) wscr[i] = 0;
-    {  // window cell -> position in the pattern order
+    if (!DCL) {  // window cell -> position in the pattern order (with the config prefix in LDS: read from there, DC_OFF_IPAT)
       const int* gdc = a.gdc + cfg_off;
       uint8_t* ipat = smem + a.fl.ip;
       const int hr = gdc[DC_OBS_H] >> 1, wr = gdc[DC_OBS_W] >> 1, ow = gdc[DC_OBS_W], op = gdc[DC_OFF_PATTERN];
       for (int p = tid; p < NP; p += nt) {
         const uint32_t packed = (uint32_t)gdc[op + p];
         const int dr = (int)(packed & 0xFF) - 8, dcc = (int)((packed >> 8) & 0xFF) - 8;
-        ipat[(dr + hr) * ow + dcc + wr] = (uint8_t)p;
+        ipat[(dr + hr) * (ow | 1) + dcc + wr] = (uint8_t)p;
       }
     }
     float* tokacc = (float*)(smem + a.fl.tk);
@@ -634,12 +698,16 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
 
   // ---- P1: actions (one wave) ------------------------------------------------------------------------------------
-  if (wave == actor) {  // (65536: timing / counter ablation, results wrong on purpose)
+  if ((int)(threadIdx.x >> 6) == actor) {  // (65536: timing / counter ablation, results wrong on purpose)
     KArgs a;
+    MG_PHASE_IDS
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
     if (!(a.diag & 65536)) {  // (65536: timing / counter ablation, results wrong on purpose)
+#ifdef MG_PRIO_ACT
+    __builtin_amdgcn_s_setprio(MG_PRIO_ACT);
+#endif
     uint32_t w = 0;
     {
       const int j = (int)env.mt_idx + lane;
@@ -659,6 +727,9 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       l.flags[3] = n_pending;
       if (env.error) atomicOr(&a.status[0], env.error);
     }
+#ifdef MG_PRIO_ACT
+    __builtin_amdgcn_s_setprio(0);
+#endif
     }
   }
   __syncthreads();
@@ -666,17 +737,24 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   // ---- P2: assembler uses (one wave) -----------------------------------------------------------------------------------
   {
     KArgs a;
+    MG_PHASE_IDS
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
     MG_STAMP(2);
     const int n_uses = l.flags[3];
     if (n_uses > 0) {  // block-uniform
+#ifdef MG_PRIO_USES
+      __builtin_amdgcn_s_setprio(MG_PRIO_USES);
+#endif
       Ctx cx;
       mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
       cx.grid = nullptr;
       mg_fused_uses(a, l, cx, n_uses, lane, wave == actor ? 0 : 1);  // (ends with a workgroup barrier)
       mg_flush_stats(a, l, cx, e, tid, nt);
+#ifdef MG_PRIO_USES
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     MG_STAMP(3);
   }
@@ -684,6 +762,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   // ---- P3: observations, rewards, flags -----------------------------------------------------------------------------
   {
     KArgs a;
+    MG_PHASE_IDS
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     __syncthreads();  // (the use scratch becomes the token lists)
@@ -693,6 +772,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
   {
     KArgs a;
+    MG_PHASE_IDS
     Lds l;
     mg_fused_phase<DCL>(a, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + a.env_base;
@@ -702,6 +782,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   }
   {
     KArgs b;
+    MG_PHASE_IDS
     Lds l;
     mg_fused_phase<DCL>(b, l, smem, H, W, env.map_id, max_steps, cfg_off);
     const int e = blockIdx.x + b.env_base;

@@ -675,13 +675,11 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         }
         h->fused_w1 = h->no_modifiers && c.A <= 8 && h->lds_fused_w1 <= LDS_MAX;
         if (const char* w1 = getenv("MG_FUSED_W1")) h->fused_w1 = h->no_modifiers && w1[0] == '1' && h->lds_fused_w1 <= LDS_MAX;
-        // 16 workgroups per CU (64 registers, some spilled) pay when the environments are exactly one round of them;
-        // with fewer (groups stepped on several streams fill each other's tails) or more (several rounds anyway) the
-        // 14-per-CU build without vector spills is the faster one.  MG_FUSED_O7=0/1 overrides.
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, h->device));
-        const long long cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        h->fused_o7 = !(h->E > 14 * cus && h->E <= 16 * cus);
+        // The builds with the larger register budget (7 waves per SIMD, 72 registers, 92 scalar registers; 6 waves with
+        // limit modifiers) are the default.  The 8-wave builds (64 registers and, on this hardware, 76 scalar ones) spill
+        // in every phase: they won in round 2 for exactly one round of 16 workgroups per CU, and lose everywhere since the
+        // round-3 kernel (one launch over 4096 environments: 0.0595 against 0.0645 ms).  MG_FUSED_O7=0 selects them.
+        h->fused_o7 = true;
         if (const char* o7 = getenv("MG_FUSED_O7")) h->fused_o7 = o7[0] == '1';
       }
     }

@@ -26,6 +26,7 @@ enum MgDc {
   // Clipper (systems/clipper.hpp): present flag, configured length scale (0 = from the map's sparsity), cutoff in units
   // of the length scale, clip period, and the unclipping protocols as (protocol record, key lo, key hi) triples
   DC_CLIPPER, DC_CLIP_LENGTH, DC_CLIP_CUTOFF, DC_CLIP_PERIOD, DC_N_UNCLIP, DC_OFF_UNCLIP,
+  DC_OFF_IPAT,  // inverse observation pattern, one byte per window cell (row-major): the cell's position in the pattern order
   DC_HEADER_WORDS
 };
 // group record
@@ -299,6 +300,21 @@ inline std::vector<int32_t> mg_build_dcfg(const MgConfig& c) {
     int o = b.reserve((int)tb.size());
     for (size_t i = 0; i < tb.size(); i++) b.w[(size_t)o + i] = tb[i];
     H(DC_OFF_UNCLIP) = o;
+  }
+  {  // (inside the LDS-staged prefix: the fused kernel's agent scatter reads it per observer)
+    std::vector<int32_t> pat = mg_pattern(c.obs_h, c.obs_w);
+    // (an even window's offsets still run over -h/2 .. h/2: the table is (h | 1) x (w | 1))
+    const int ih = c.obs_h | 1, iw = c.obs_w | 1;
+    std::vector<uint8_t> inv((size_t)ih * iw + 3, 0);
+    for (size_t p = 0; p < pat.size(); p++) {
+      const int dr = (pat[p] & 0xFF) - 8, dcc = ((pat[p] >> 8) & 0xFF) - 8;
+      inv[(size_t)(dr + c.obs_h / 2) * iw + (size_t)(dcc + c.obs_w / 2)] = (uint8_t)p;
+    }
+    const int nw = (ih * iw + 3) / 4;
+    int o = b.reserve(nw);
+    for (int i = 0; i < nw; i++)
+      b.w[(size_t)o + i] = (int32_t)((uint32_t)inv[4 * i] | ((uint32_t)inv[4 * i + 1] << 8) | ((uint32_t)inv[4 * i + 2] << 16) | ((uint32_t)inv[4 * i + 3] << 24));
+    H(DC_OFF_IPAT) = o;
   }
   H(DC_OBS_WORDS) = (int32_t)((b.w.size() + 3) & ~(size_t)3);
   while (b.w.size() % 4) b.w.push_back(0);

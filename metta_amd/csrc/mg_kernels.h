@@ -183,7 +183,7 @@ __host__ __device__ inline size_t mg_carve_fused(FusedLds* f, int A, int SG, int
   if (u_b < 624 * 4) u_b = 624 * 4;
   size_t u = take(u_b);
   const int WS = NP <= 128 ? 128 : ((NP + 63) & ~63);  // (two full rounds: the encoder reads them without a bounds test)
-  size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP);
+  size_t ws = take((size_t)nwaves * 2 * WS), ip = take((size_t)NP + 64);  // (ip: (h | 1) x (w | 1) <= h w + h + w + 1 bytes, windows are at most 15 x 15)
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16);
   size_t gd = take((size_t)SG * 4), da = take((size_t)A * 4), dm = take((size_t)A * 4), ord = take((size_t)A);
   size_t fl = take(32), su = take((size_t)A);
@@ -568,7 +568,7 @@ __device__ __forceinline__ void mg_window_lookup_direct(const KArgs& a, const Ld
   const bool inwin = lane < a.A && jr >= -ec.hr && jr <= ec.hr && jc >= -ec.wr && jc <= ec.wr;
   int pj = 0;
   if (inwin) {
-    pj = l.ipat[__mul24(jr + ec.hr, ec.ow) + jc + ec.wr];
+    pj = l.ipat[__mul24(jr + ec.hr, ec.ow | 1) + jc + ec.wr];  // (the table is (h | 1) x (w | 1): DC_OFF_IPAT)
     ws[pj] = (uint8_t)(lane + 1);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -778,6 +778,7 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
   {
     uint32_t meta[group][NR], rc[group];
+#ifndef MG_ENC_SEQ  // (the lookups of both agents of a pair up front; MG_ENC_SEQ: one agent at a time, fewer live registers)
 #pragma unroll
     for (int h = 0; h < group; h++) {
       if (DIRECT)
@@ -785,8 +786,15 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
       else
         mg_window_lookup<NR, PAIRS, CT>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
     }
+#endif
 #pragma unroll
     for (int h = 0; h < group; h++) {
+#ifdef MG_ENC_SEQ
+      if (DIRECT)
+        mg_window_lookup_direct<NR>(a, l, ec, me0 + h, dlt, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS, gm, Wp);
+      else
+        mg_window_lookup<NR, PAIRS, CT>(a, l, ec, me0 + h, pk, lane, meta[h], rc[h]);
+#endif
       const int ai = a0 + h;
       // The row sits in LDS at the same 16-byte phase as in HBM, so that it leaves as aligned 16-byte stores.
       const uint32_t roff = roff0 + (uint32_t)(h * row_bytes);
