@@ -573,6 +573,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
   int H, W, act = 0, NW_, actor = 0, max_steps, cfg_off;
   uint32_t mt_raw = 0;
   uint4 v1 = make_uint4(0, 0, 0, 0), v2 = v1;
+  float tok0 = 0.f;  // tokens_* accumulators of the running episode (threads 0..2), requested with the first loads
   bool do_reset, slots;
 
   // ---- P0: stage.  In blocks that each read their own few kernel arguments (see mg_fused_kargs) --------------------
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) d0[i] = s0[i];  // padded to x4
     }
     if (lane < a.A) act = a.actions[(size_t)e * a.A + lane];  // (every wave: cheaper than choosing the acting wave first)
+    if (tid < 3) tok0 = a.gstats[(size_t)e * a.SG + tid];
     env = a.env[e];
     {  // the env words are the same in every lane: pin them to scalar registers.  Left to itself the allocator may
        // carry them through the phases as vector registers and spill them there -- 16 bytes per LANE per spill.
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       env.error = (uint32_t)__builtin_amdgcn_readfirstlane((int)env.error);
     }
     do_reset = a.auto_reset && env.done;  // block-uniform
+    MG_STAMP(11);
   }
   if (do_reset) {  // P0b: episode restart (rare); rewrites the records
     KArgs a;
@@ -646,6 +649,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
       const uint4* __restrict__ s1 = (const uint4*)(a.agents + (size_t)e * a.A);
       for (int i = tid; i < n1; i += nt) dag[i] = s1[i];
     }
+    MG_STAMP(12);
   }
   {  // P0d: per-step LDS state
     KArgs a;
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(MG_FUSED_THREADS, MG_FUSED_OCC) void mg_step_fused_
     }
     float* tokacc = (float*)(smem + a.fl.tk);
     int* flags = (int*)(smem + a.fl.fl);
-    if (tid < 3) tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+    if (tid < 3) tokacc[tid] = do_reset ? a.gstats[(size_t)e * a.SG + tid] : tok0;  // (a restart rewrote them)
     if (tid == 0) {
       flags[3] = 0;
       flags[2] = 0;

@@ -51,3 +51,6 @@ print("P0 percentiles [10,50,90,99]:", np.percentile(d[:,0],[10,50,90,99]), " en
 print("P1 percentiles [50,90,99,100]: no queued use", np.percentile(p1[~has],[50,90,99,100]), " with", np.percentile(p1[has],[50,90,99,100]))
 big = p1 > 30000
 print("blocks with P1 > 30k:", int(big.sum()), " of which with queued uses", int((big&has).sum()), " P0 median of those", np.median(d[big,0]) if big.any() else 0, " count hist", np.bincount(cnt[big&has].astype(int))[:8] if (big&has).any() else 0)
+
+p0a = out[:,11].astype(np.int64)-out[:,0].astype(np.int64); p0c = out[:,12].astype(np.int64)-out[:,11].astype(np.int64); p0d = out[:,1].astype(np.int64)-out[:,12].astype(np.int64)
+print("P0 split medians: a (loads issued, env words in)", np.median(p0a), " b+c (restart test, map, rng window, records to LDS)", np.median(p0c), " d (LDS init, barrier)", np.median(p0d))
