@@ -339,3 +339,44 @@ def test_curriculum_vecenv_builds_each_task_its_own_map():
     assert len(cur.updates) >= 9 and all(len(s) >= 3 for s in seen), "every episode had a map of its own"
     b.check_errors()
     env.close()
+
+
+def test_task_with_limit_modifiers_keeps_the_modifier_build_across_new_pools():
+    """a task with inventory-limit modifiers written into a configuration slot must keep the handle off the
+    modifier-free fused kernels, also when the pool is (re)built afterwards -- `mg_set_maps` used to recompute the flag
+    from the handle's own configuration only.  Parity of the modifier task against the oracle after a second
+    `set_maps`, and the step path names the build with modifiers."""
+    from metta_amd.batch import MettaGridBatch
+    from oracle.mg_oracle import make_oracle_env
+
+    tasks = _tasks()
+    mod = copy.deepcopy(tasks[0])
+    mod.game.max_steps = 30
+    mod.game.agent.inventory.initial = {"ore_red": 6, "battery_red": 1}
+    mod.game.agent.inventory.limits["ore"] = ResourceLimitsConfig(limit=4, resources=["ore_red"], modifiers={"battery_red": 3})
+    maps = load_map_pool()[:2]
+    E, A = 2, 24
+    b = MettaGridBatch(tasks[0], E, maps, device=0, config_slots=2)
+    assert "nomod" in b.step_path()
+    b.write_config_slot(1, mod)
+    assert "fused" in b.step_path() and "nomod" not in b.step_path()
+    b.set_maps(maps)  # a new pool on the live handle: the slot (and its task) survives it
+    assert "fused" in b.step_path() and "nomod" not in b.step_path(), b.step_path()
+    b.assign_map_configs([0, 1], [0, 1])
+    b.reset(seeds=[11, 12], map_ids=[0, 1])
+    b.set_auto_reset(True, 0)  # every environment stays on its map (and task)
+    comps = [compile_game(tasks[0], init_obs_passes=2), compile_game(mod, init_obs_passes=2)]
+    oras = [make_oracle_env(comps[m], comps[m].encode_map(maps[m]), s) for m, s in ((0, 11), (1, 12))]
+    _compare_step(b, oras, 0, A)
+    rs = np.random.RandomState(3)
+    for t in range(1, 70):
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        for e in range(E):
+            if oras[e].terminals.all() or oras[e].truncations.all():
+                oras[e] = make_oracle_env(comps[e], comps[e].encode_map(maps[e]), (11, 12)[e])
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+    _compare_state(b, oras, 69)
+    b.check_errors()
+    b.close()

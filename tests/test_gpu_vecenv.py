@@ -447,3 +447,46 @@ def test_groups_on_their_own_streams_equal_one_handle():
     for b in groups + [one]:
         b.check_errors()
         b.close()
+
+
+def test_async_send_keeps_the_action_tensor_alive_for_the_side_stream():
+    """`AsyncDeviceVecEnv.send` steps a group on its own stream and `mg_step_actions` reads the caller's action
+    tensor in place; the caching allocator only knows the stream the tensor was allocated on.  The caller drops the
+    tensor right after `send()` (rollout_phase does) and allocates again: without `record_stream` the block is handed
+    out while the step may still be waiting to read it.  Here the group's stream is held back by a sleep kernel, the
+    tensor is dropped and a same-sized tensor of invalid actions is allocated at once; the environments must still
+    have been stepped with the actions that were sent (compared with a twin vecenv that keeps its tensors)."""
+    import torch
+
+    from metta_amd.builder import make_arena
+    from metta_amd.vecenv import AsyncDeviceVecEnv
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 50
+    pool = load_map_pool()[:4]
+    env = AsyncDeviceVecEnv(cfg, 8, 4, device=0, seed=3, maps=pool, early_reset=False)
+    twin = AsyncDeviceVecEnv(cfg, 8, 4, device=0, seed=3, maps=pool, early_reset=False)
+    env.async_reset(3)
+    twin.async_reset(3)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    keep = []
+    n = env.agents_per_batch
+    for t in range(40):
+        o1 = env.recv()[0]
+        o2 = twin.recv()[0]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2), f"observations differ at turn {t}"
+        acts = torch.randint(0, 5, (n,), generator=g, device="cuda", dtype=torch.int32)
+        a2 = acts.clone()
+        keep.append(a2)
+        twin.send(a2)
+        k = env._next
+        with torch.cuda.stream(env._streams[k]):
+            torch.cuda._sleep(2_000_000)  # the group's stream is busy for a while: its step has not read the actions yet
+        env.send(acts)
+        del acts
+        junk = torch.full((n,), -1, device="cuda", dtype=torch.int32)  # same size class: the freed block, if it was freed
+        keep.append(junk)
+    torch.cuda.synchronize()
+    env.close()
+    twin.close()
