@@ -294,9 +294,8 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
         bool ok = false;
         if (act < 0 || act >= n_actions) {
           // _handle_invalid_action runs once per priority level (the check precedes the priority filter)
-          mg_stat_add(cx, ai, cx.AS.invalid(), passes);
-          int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
-          mg_stat_add(cx, ai, cx.AS.invalid_variant(variant), passes);
+          // (only the agent's own turn touches these slots)
+          mg_count_invalid(cx.astats + (size_t)ai * cx.SA, cx.AS, act, n_actions, passes);
         } else {
           ok = mg_handle_action(cx, ai, dc[oa + 2 * act], dc[oa + 2 * act + 1]);
           if (ok) l.exec[ai] = act;

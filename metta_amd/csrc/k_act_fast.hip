@@ -290,12 +290,7 @@ __global__ __launch_bounds__(MG_FAST_THREADS) void mg_act_fast_kernel(KArgs a) {
       rec->fail[0] = fail0; rec->fail[1] = fail1; rec->fail[2] = fail2;
     } else {
       // _handle_invalid_action, once per priority level (bindings/mettagrid_c.cpp:565-570,599-608)
-      const MgAgentSlots AS{a.R, a.NG};
-      const int passes = dc[DC_MAX_PRIORITY] + 1;
-      float* row = a.astats + g * a.SA;
-      int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
-      row[AS.invalid()] += (float)passes;
-      row[AS.invalid_variant(variant)] += (float)passes;
+      mg_count_invalid(a.astats + g * a.SA, MgAgentSlots{a.R, a.NG}, act, n_actions, dc[DC_MAX_PRIORITY] + 1);
     }
     a.exec[g] = ok ? act : 0;
     a.success[g] = ok ? 1 : 0;

@@ -388,14 +388,10 @@ __device__ __forceinline__ uint32_t mg_fused_act(const KArgs& a, const Lds& l, D
       *(uint4*)rec = f0;
       rec->max_swm = max_swm;
     } else {
-      // _handle_invalid_action, once per priority level (bindings/mettagrid_c.cpp:565-570,599-608).  Atomic adds like
-      // every other direct stat update of this launch (small integers: exact and order independent).
-      const MgAgentSlots AS{a.R, a.NG};
-      const int passes = dc[DC_MAX_PRIORITY] + 1;
+      // _handle_invalid_action, once per priority level (bindings/mettagrid_c.cpp:565-570,599-608).  (No use of this
+      // launch touches these slots: plain updates.)
       float* row = a.astats + ((size_t)(blockIdx.x + a.env_base) * A + lane) * a.SA;
-      int variant = act == -1 ? 0 : (act >= n_actions && act < n_actions + 7) ? 1 + (act - n_actions) : 8;
-      atomicAdd(&row[AS.invalid()], (float)passes);
-      atomicAdd(&row[AS.invalid_variant(variant)], (float)passes);
+      mg_count_invalid(row, MgAgentSlots{a.R, a.NG}, act, n_actions, dc[DC_MAX_PRIORITY] + 1);
     }
     l.exec[lane] = ok ? act : 0;
     l.succ[lane] = ok ? 1 : 0;

@@ -39,6 +39,10 @@ enum MgFid {
 // ---------------------------------------------------------------------------------------------------------
 #define MG_NUM_HANDLERS 3
 #define MG_INVALID_VARIANTS 9  // action.invalid_index.<id> for id = -1, n_actions .. n_actions+6, "other"
+// Any other id: the reference makes one key per id (mettagrid_c.cpp:565-570).  The agent's stat row ends with
+// MG_INVALID_TABLE (id, count) pairs -- the id as raw int32 bits in the f32 slot -- filled first come first kept; a
+// further distinct id of one agent in one episode counts under "action.invalid_index.other".
+#define MG_INVALID_TABLE 4
 struct MgAgentSlots {
   int R, G;
   constexpr int success(int h) const { return h; }
@@ -68,7 +72,9 @@ struct MgAgentSlots {
   constexpr int attack_hit_by(int g) const { return base_g() + 1 * G + g; }
   constexpr int attack_blocked_by(int g) const { return base_g() + 2 * G + g; }
   constexpr int transfer_to(int g, int r) const { return base_g() + 3 * G + g * R + r; }
-  constexpr int count() const { return base_g() + 3 * G + G * R; }
+  constexpr int invalid_table_id(int k) const { return base_g() + 3 * G + G * R + 2 * k; }
+  constexpr int invalid_table_count(int k) const { return base_g() + 3 * G + G * R + 2 * k + 1; }
+  constexpr int count() const { return base_g() + 3 * G + G * R + 2 * MG_INVALID_TABLE; }
 };
 struct MgGameSlots {
   int R, C;  // C = number of map cell codes (objects.<cell name>)

@@ -109,6 +109,30 @@ __device__ __forceinline__ void mg_stat_add(Ctx& cx, int ai, int slot, int delta
   atomicOr(&cx.atouched[ai * cx.TW + (slot >> 5)], 1u << (slot & 31));
 }
 
+// _handle_invalid_action (bindings/mettagrid_c.cpp:565-570): "action.invalid_index" and "action.invalid_index.<id>",
+// `passes` times (once per priority level, :599-608).  `row` = the agent's stat row in HBM; one thread per agent, so
+// plain read-modify-writes (a key exists once its value is non-zero; see MG_INVALID_TABLE for ids without a slot).
+__device__ inline void mg_count_invalid(float* row, const MgAgentSlots AS, int act, int n_actions, int passes) {
+  row[AS.invalid()] += (float)passes;
+  if (act == -1 || (act >= n_actions && act < n_actions + 7)) {
+    row[AS.invalid_variant(act == -1 ? 0 : 1 + (act - n_actions))] += (float)passes;
+    return;
+  }
+  for (int k = 0; k < MG_INVALID_TABLE; k++) {
+    const float cnt = row[AS.invalid_table_count(k)];
+    if (cnt == 0.f) {
+      row[AS.invalid_table_id(k)] = __int_as_float(act);
+      row[AS.invalid_table_count(k)] = (float)passes;
+      return;
+    }
+    if (__float_as_int(row[AS.invalid_table_id(k)]) == act) {
+      row[AS.invalid_table_count(k)] = cnt + (float)passes;
+      return;
+    }
+  }
+  row[AS.invalid_variant(8)] += (float)passes;
+}
+
 __device__ __forceinline__ DAgent* mg_holder(const Ctx& cx, int h) { return h < cx.A ? &cx.ag[h] : &cx.ch[h - cx.A]; }
 
 // ---- small list helpers over the dcfg stream ----------------------------------------------------------------

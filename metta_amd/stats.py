@@ -10,11 +10,15 @@ from __future__ import annotations
 
 HANDLER_NAMES = ["noop", "move", "change_vibe"]
 INVALID_VARIANTS = 9
+INVALID_TABLE = 4  # MG_INVALID_TABLE: (id, count) slot pairs at the end of an agent's row for ids without a slot of their own
+INVALID_TABLE_MARK = "\x00action.invalid_index.#"  # name of the k-th count slot (never a key: see invalid_table_keys)
 
 
 def agent_slot_names(resource_names: list[str], group_names: list[str], own_group: str, n_actions: int) -> list[str]:
     R, G = len(resource_names), len(group_names)
-    names: list[str] = [""] * (26 + 7 * R + 3 * G + G * R)
+    names: list[str] = [""] * (26 + 7 * R + 3 * G + G * R + 2 * INVALID_TABLE)
+    for k in range(INVALID_TABLE):  # (the id slots stay unnamed)
+        names[26 + 7 * R + 3 * G + G * R + 2 * k + 1] = f"{INVALID_TABLE_MARK}{k}"
     for h, hn in enumerate(HANDLER_NAMES):
         names[h] = f"action.{hn}.success"
         names[3 + h] = f"action.{hn}.failed"
@@ -63,3 +67,19 @@ def game_slot_names(resource_names: list[str], cell_names: list[str]) -> list[st
     names += [f"chest.{r}.amount" for r in resource_names]
     assert len(names) == 3 + C + 4 * R
     return names
+
+
+def invalid_table_keys(values_row) -> dict[str, float]:
+    """The reference's `action.invalid_index.<id>` keys (mettagrid_c.cpp:565-570) held in the (id, count) pairs at the end
+    of one agent's slot row: ids are raw int32 bits in the f32 slots."""
+    import numpy as np
+
+    row = np.ascontiguousarray(values_row, dtype=np.float32)
+    n = row.shape[0]
+    out: dict[str, float] = {}
+    for k in range(INVALID_TABLE):
+        cnt = float(row[n - 2 * INVALID_TABLE + 2 * k + 1])
+        if cnt != 0.0:
+            ident = int(row[n - 2 * INVALID_TABLE + 2 * k : n - 2 * INVALID_TABLE + 2 * k + 1].view(np.int32)[0])
+            out[f"action.invalid_index.{ident}"] = cnt
+    return out

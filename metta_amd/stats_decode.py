@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from metta_amd.stats import invalid_table_keys
+
 
 def decode_episode_stats(compiled, agent_values, agent_touched, game_values, game_touched, agent_groups) -> dict:
     game = {
@@ -14,5 +16,11 @@ def decode_episode_stats(compiled, agent_values, agent_touched, game_values, gam
     agents = []
     for a in range(np.asarray(agent_values).shape[0]):
         names = compiled.agent_slot_names[agent_groups[a]]
-        agents.append({names[i]: float(agent_values[a][i]) for i in np.nonzero(np.asarray(agent_touched[a]))[0].tolist()})
+        d = {
+            names[i]: float(agent_values[a][i])
+            for i in np.nonzero(np.asarray(agent_touched[a]))[0].tolist()
+            if names[i] and not names[i].startswith("\x00")
+        }
+        d.update(invalid_table_keys(agent_values[a]))  # action.invalid_index.<id> for ids without a slot of their own
+        agents.append(d)
     return {"game": game, "agent": agents}

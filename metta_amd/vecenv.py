@@ -32,6 +32,7 @@ from metta_amd.batch import MettaGridBatch
 from metta_amd.compile import compile_game
 from metta_amd.config import MettaGridConfig
 from metta_amd.spaces import Box, Discrete, joint_space
+from metta_amd.stats import INVALID_TABLE, invalid_table_keys
 
 RESET, SEND, RECV = 0, 2, 3
 
@@ -375,7 +376,8 @@ class MettaGridDeviceVecEnv:
                 names = c.agent_slot_names[0]
                 sums = vals.sum(axis=0)
                 for s in np.nonzero(at[i].any(axis=0))[0].tolist():
-                    agent[names[s]] = float(sums[s]) / A
+                    if names[s] and names[s][0] != "\x00":
+                        agent[names[s]] = float(sums[s])
             else:  # slot names carry the group's name: sum per group, merge by key
                 groups = np.asarray(self._map_groups(prev_map))
                 for g in np.unique(groups).tolist():
@@ -383,8 +385,14 @@ class MettaGridDeviceVecEnv:
                     names = c.agent_slot_names[g]
                     sums = vals[sel].sum(axis=0)
                     for s in np.nonzero(at[i][sel].any(axis=0))[0].tolist():
-                        agent[names[s]] = agent.get(names[s], 0.0) + float(sums[s])
-                agent = {k: v / A for k, v in agent.items()}
+                        if names[s] and names[s][0] != "\x00":
+                            agent[names[s]] = agent.get(names[s], 0.0) + float(sums[s])
+            n_tab = 2 * INVALID_TABLE
+            if av[i][:, -n_tab + 1 :: 2].any():  # action.invalid_index.<id> of ids without a slot (rare)
+                for row in av[i]:
+                    for k, v in invalid_table_keys(row).items():
+                        agent[k] = agent.get(k, 0.0) + v
+            agent = {k: v / A for k, v in agent.items()}
             game = {c.game_slot_names[s]: float(gv[i, s]) for s in np.nonzero(gt[i])[0].tolist()}
             mean_reward = float(rew[i].mean())
             self._per_label_rewards[self._label] = mean_reward

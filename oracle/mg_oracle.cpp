@@ -1384,8 +1384,27 @@ void Env::step(const int32_t* actions) {
         Agent& a = agents[ai];
         a.stats.add(AS.invalid(), 1.f);
         int nA = (int)cfg.actions.size();
-        int variant = act == -1 ? 0 : (act >= nA && act < nA + 7) ? 1 + (act - nA) : 8;
-        a.stats.add(AS.invalid_variant(variant), 1.f);
+        if (act == -1 || (act >= nA && act < nA + 7)) {
+          a.stats.add(AS.invalid_variant(act == -1 ? 0 : 1 + (act - nA)), 1.f);
+        } else {
+          // "action.invalid_index.<id>" for any other id: (id, count) pairs at the end of the slot array, the id as
+          // raw int32 bits (MG_INVALID_TABLE in mg_blob.h; metta_amd/stats.py names the keys)
+          bool placed = false;
+          for (int k = 0; k < MG_INVALID_TABLE && !placed; k++) {
+            const int si = AS.invalid_table_id(k), sc = AS.invalid_table_count(k);
+            int32_t held;
+            std::memcpy(&held, &a.stats.v[(size_t)si], 4);
+            if (a.stats.v[(size_t)sc] == 0.f) {
+              std::memcpy(&a.stats.v[(size_t)si], &act, 4);
+              a.stats.add(sc, 1.f);
+              placed = true;
+            } else if (held == act) {
+              a.stats.add(sc, 1.f);
+              placed = true;
+            }
+          }
+          if (!placed) a.stats.add(AS.invalid_variant(8), 1.f);
+        }
         action_success[ai] = 0;
         continue;
       }

@@ -533,3 +533,40 @@ def test_full_size_properties():
         assert np.array_equal(obs[e + 512 * 3], o.obs)
     b1.close()
     b2.close()
+
+
+@pytest.mark.parametrize("path_env", [{}, {"MG_NO_FUSED": "1"}, {"MG_FORCE_GENERAL": "1"}], ids=["fused", "fast", "general"])
+def test_invalid_action_ids_keep_their_keys(path_env, monkeypatch):
+    """`action.invalid_index.<id>` for ids far from the action table (mettagrid_c.cpp:565-570): the (id, count) pairs at
+    the end of the agent's stat row, on every step path, against the oracle (which
+    tests/test_oracle_golden.py::test_invalid_action_ids_make_the_reference_keys pins to the reference's core)."""
+    from metta_amd.batch import MettaGridBatch
+    from oracle.mg_oracle import make_oracle_env
+
+    for k, v in path_env.items():
+        monkeypatch.setenv(k, v)
+    cfg = make_arena(24)
+    cfg.game.max_steps = 45
+    comp = compile_game(cfg, init_obs_passes=2)
+    maps = load_map_pool()[:2]
+    E, A = 2, 24
+    b = MettaGridBatch(cfg, E, maps, device=0, seeds=[3, 4], map_ids=[0, 1])
+    b.set_auto_reset(True, 1)
+    oras = [make_oracle_env(comp, comp.encode_map(maps[m]), s) for m, s in ((0, 3), (1, 4))]
+    wild = [1000, -7, 2**31 - 1, -(2**31), 5, 11, -1, 77, 78]
+    rs = np.random.RandomState(2)
+    for t in range(1, 44):
+        acts = rs.randint(0, 5, size=(E, A)).astype(np.int32)
+        mask = rs.rand(E, A) < 0.15
+        acts[mask] = np.asarray(wild, dtype=np.int64)[rs.randint(len(wild), size=int(mask.sum()))].astype(np.int32)
+        for e in range(E):
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, A)
+    for e in range(E):
+        d = stats_equal(b.get_episode_stats(e), oras[e].get_episode_stats(), ignore_invalid_variants=False)
+        assert d is None, d
+        keys = set().union(*[set(a) for a in b.get_episode_stats(e)["agent"]])
+        assert "action.invalid_index.1000" in keys and "action.invalid_index.-2147483648" in keys
+    b.check_errors()
+    b.close()

@@ -181,3 +181,42 @@ def test_clipper_known_answers_of_the_reference():
     assert L.mgo_clipper_auto_length_scale(50, 50, 9) == 8
     # GridSizeScaling: 100 x 100 against 25 x 25 with 25 assemblers each: four times the scale (integer division)
     assert L.mgo_clipper_auto_length_scale(100, 100, 25) // 4 == L.mgo_clipper_auto_length_scale(25, 25, 25)
+
+
+def test_invalid_action_ids_make_the_reference_keys():
+    """`action.invalid_index.<id>` (mettagrid_c.cpp:565-570): the reference makes one key per offending id.  Ids next to the
+    action table have slots of their own; any other id lands in the (id, count) pairs at the end of the agent's row
+    (MG_INVALID_TABLE = 4 distinct ids per agent and episode, a fifth counts under `.other` -- the one deviation left).
+    Against the reference's compiled core, exact keys and counts."""
+    from oracle.ref_bridge import RefEnv, have_reference
+
+    if not have_reference():
+        pytest.skip("oracle/_ref not built (run `make -C oracle ref` where /root/reference exists)")
+    cfg = make_arena(24)
+    comp = compile_game(cfg, init_obs_passes=2)
+    grid = cfg.game.map_builder.build(np.random.default_rng(1))
+    ref = RefEnv(cfg.game, grid, 7)
+    ora = make_oracle_env(comp, comp.encode_map(grid), 7)
+    wild = [1000, -7, 2**31 - 1, -(2**31), 5, 11]  # (5 = n_actions, 11 = n_actions + 6: ids with slots of their own)
+    rs = np.random.RandomState(0)
+    for t in range(60):
+        acts = rs.randint(0, 5, size=24).astype(np.int32)
+        for a in range(0, 24, 3):  # agent a sees at most 4 distinct wild ids (a % 4 picks them), agent 0 sees all of them
+            pool = wild if a != 0 else wild + [77, 78, 79]
+            if rs.randint(3) == 0:
+                acts[a] = pool[rs.randint(len(pool))] if a == 0 else [wild[a % 4], wild[(a + 1) % 4], 5, 11, -1][rs.randint(5)]
+        ref.step(acts)
+        ora.step(acts)
+        assert np.array_equal(ref.obs, ora.obs)
+    rstats, ostats = ref.env.get_episode_stats(), ora.get_episode_stats()
+    for a in range(1, 24):
+        rk = {k: v for k, v in rstats["agent"][a].items() if k.startswith("action.invalid_index")}
+        ok = {k: v for k, v in ostats["agent"][a].items() if k.startswith("action.invalid_index")}
+        assert rk == ok, (a, rk, ok)
+    # agent 0 met more than four distinct ids without a slot: the first four keep their keys, the rest fold into .other
+    r0 = {k: v for k, v in rstats["agent"][0].items() if k.startswith("action.invalid_index")}
+    o0 = {k: v for k, v in ostats["agent"][0].items() if k.startswith("action.invalid_index")}
+    assert o0["action.invalid_index"] == r0["action.invalid_index"]
+    folded = o0.pop("action.invalid_index.other", 0.0)
+    assert all(r0[k] == v for k, v in o0.items())
+    assert folded == sum(v for k, v in r0.items() if k not in o0)
