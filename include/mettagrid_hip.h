@@ -88,6 +88,15 @@ int mg_set_config_slots(mg_handle* h, int num_slots, int headroom_words);
  * the idle twin). */
 int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t cfg_words, void* stream);
 
+/* The same in two halves, for curricula that hand out a few distinct tasks thousands of times
+ * (`CurriculumEnv` draws a task per episode, curriculum_env.py:111-126; with thousands of environments ten episodes end
+ * per step): mg_register_config compiles a task ONCE into a device-side registry and returns its id (host-synchronous,
+ * the checks and kernel-choice effects of mg_write_config_slot happen here); mg_write_config_slots then copies
+ * registered streams into `n` slots with one kernel and rebuilds the templates of the map slots that play them with one
+ * more, stream-ordered, no host synchronisation.  Same rule as above: only slots no environment is on. */
+int mg_register_config(mg_handle* h, const int32_t* cfg_blob, size_t cfg_words, int32_t* config_id);
+int mg_write_config_slots(mg_handle* h, int n, const int32_t* slots, const int32_t* config_ids, void* stream);
+
 /* map_cfg[map_ids[i]] = cfg_slots[i] for i < n, and rebuild those map slots' episode-start templates (host arrays;
  * stream-ordered).  Same rule: only map slots no environment is on. */
 int mg_assign_map_configs(mg_handle* h, int n, const int32_t* map_ids, const int32_t* cfg_slots, void* stream);

@@ -221,6 +221,26 @@ class MettaGridBatch:
         blob = np.ascontiguousarray(comp.blob, dtype=np.int32)
         self._check(self.L.mg_write_config_slot(self._h, int(slot), _p(blob, ct.c_int32), blob.size, self._stream()))
 
+    def register_config(self, cfg) -> int:
+        """Compile `cfg` (a MettaGridConfig, or a CompiledGame) once into the handle's device-side registry
+        (`mg_register_config`); the id goes to `write_config_slots`.  Same checks as `write_config_slot`."""
+        comp = cfg if isinstance(cfg, CompiledGame) else compile_game(cfg, init_obs_passes=self._init_obs_passes)
+        if comp.agent_slot_names != self.compiled.agent_slot_names or comp.game_slot_names != self.compiled.game_slot_names:
+            raise RuntimeError("mg_register_config: the task's configuration differs from the handle's in the statistics layout")
+        blob = np.ascontiguousarray(comp.blob, dtype=np.int32)
+        cid = ct.c_int32()
+        self._check(self.L.mg_register_config(self._h, _p(blob, ct.c_int32), blob.size, ct.byref(cid)))
+        return int(cid.value)
+
+    def write_config_slots(self, slots: Sequence[int], config_ids: Sequence[int]) -> None:
+        """Registered configurations into many slots at once: one copy kernel + one template rebuild, stream-ordered."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        ids = np.ascontiguousarray(config_ids, dtype=np.int32)
+        if sl.shape != ids.shape or sl.ndim != 1:
+            raise RuntimeError("slots and config_ids must be 1-D and of equal length")
+        if len(sl):
+            self._check(self.L.mg_write_config_slots(self._h, len(sl), _p(sl, ct.c_int32), _p(ids, ct.c_int32), self._stream()))
+
     def assign_map_configs(self, map_ids: Sequence[int], cfg_slots: Sequence[int]) -> None:
         """Map slot map_ids[i] plays configuration slot cfg_slots[i] from its next episode start on."""
         m = np.ascontiguousarray(map_ids, dtype=np.int32)

@@ -118,6 +118,13 @@ __global__ void mg_gather_finished_kernel(KArgs a, const int* envs, uint32_t* ou
   if (threadIdx.x == 0) dst[n4] = a.fin_steps[e];
 }
 
+// mg_write_config_slots: stream of slot slots[b] <- registered stream ids[b] (stride words each, a multiple of 4)
+__global__ void mg_copy_config_kernel(int* gdc, const int* reg, const int* slots, const int* ids, int stride) {
+  const uint4* __restrict__ src = (const uint4*)(reg + (size_t)ids[blockIdx.x] * stride);
+  uint4* dst = (uint4*)(gdc + (size_t)slots[blockIdx.x] * stride);
+  for (int i = threadIdx.x; i < (stride >> 2); i += blockDim.x) dst[i] = src[i];
+}
+
 __global__ void mg_fill_u8(uint8_t* p, size_t n, uint8_t v) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -198,6 +205,10 @@ struct mg_handle {
   int base_dc_words = 0, base_obs_words = 0;
   std::vector<int32_t> base_dcfg;
   std::vector<int32_t> host_map_cfg;  // [P]
+  // registered configurations (mg_register_config): streams kept on the device, copied into slots by one kernel
+  int* d_reg = nullptr;               // [reg_cap][dc_stride]
+  int reg_cap = 0, reg_n = 0;
+  int* d_wlist = nullptr;             // [2][n_cfg_slots] staging of (slots, ids) for mg_write_config_slots
   int* d_map_cfg = nullptr;           // [P] (lives with the pool)
   int* d_tlist = nullptr;             // [P] staging for template rebuild lists (lives with the pool)
   int ts[4] = {0, 0, 0, 0};           // token-list strides TSW, TSA, TSS, TSC the pool was sized for
@@ -1076,20 +1087,21 @@ static int mg_rebuild_templates(mg_handle* h, const std::vector<int>& maps, hipS
   return 0;
 }
 
-int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t cfg_words, void* stream) {
-  if (!h || !cfg_blob) return fail("mg_write_config_slot: NULL argument");
-  if (h->n_cfg_slots < 1) return fail("mg_write_config_slot: call mg_set_config_slots first");
-  if (slot < 0 || slot >= h->n_cfg_slots) return fail("mg_write_config_slot: slot out of range");
+// A task's blob -> its device configuration stream, padded to the slot stride: parsed, checked against what the handle's
+// buffers and observation layout were sized for, and the handle's kernel choice updated (a task outside the fast class
+// moves the handle to the general kernels; a task with limit modifiers to the builds that honour them).
+static int mg_task_stream(mg_handle* h, const int32_t* cfg_blob, size_t cfg_words, const char* who, std::vector<int32_t>& dcfg) {
+  const std::string W = who;
   MgConfig v;
   try {
     v = MgConfig::parse(cfg_blob, cfg_words);
   } catch (const std::exception& ex) {
-    return fail(std::string("mg_write_config_slot: ") + ex.what());
+    return fail(W + ": " + ex.what());
   }
-  if (mg_check_supported(v, "mg_write_config_slot")) return 1;
+  if (mg_check_supported(v, who)) return 1;
   const MgConfig& c = h->cfg;
   // what sizes buffers, LDS and the observation layout must match the configuration the handle was created with
-  auto differs = [&](const char* what) { return fail(std::string("mg_write_config_slot: the task's configuration differs from the handle's in ") + what); };
+  auto differs = [&](const char* what) { return fail(W + ": the task's configuration differs from the handle's in " + what); };
   if (v.R != c.R) return differs("the number of resources");
   if (v.A != c.A) return differs("num_agents");
   if (v.T != c.T || v.obs_w != c.obs_w || v.obs_h != c.obs_h || v.token_base != c.token_base) return differs("the observation shape");
@@ -1116,17 +1128,14 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
     return differs("tokens per object (more than the pool was sized for)");
   if (!h->maps_set)  // the pool is sized later: for the widest task seen until then
     for (int i = 0; i < 4; i++) h->ts_need[i] = std::max(h->ts_need[i], ts[i]);
-  std::vector<int32_t> dcfg = mg_build_dcfg(v);
+  dcfg = mg_build_dcfg(v);
   while (dcfg.size() % 4) dcfg.push_back(0);
   KArgs& k = h->k;
   if ((int)dcfg.size() > k.dc_stride || dcfg[DC_OBS_WORDS] > k.dc_obs_words)
-    return fail("mg_write_config_slot: the task's configuration stream (" + std::to_string(dcfg.size()) + " words, prefix " +
+    return fail(W + ": the task's configuration stream (" + std::to_string(dcfg.size()) + " words, prefix " +
                 std::to_string(dcfg[DC_OBS_WORDS]) + ") exceeds the slot (" + std::to_string(k.dc_stride) + ", prefix " +
                 std::to_string(k.dc_obs_words) + "): raise headroom_words of mg_set_config_slots");
-  if (mg_use_device(h)) return 1;
-  hipStream_t st = (hipStream_t)stream;
   dcfg.resize((size_t)k.dc_stride, 0);
-  if (mg_upload(h, const_cast<int*>(k.gdc) + (size_t)slot * k.dc_stride, dcfg.data(), dcfg.size(), st)) return 1;
   // a task outside the wave-parallel / modifier-free fast paths moves the whole handle to the general kernels
   if (k.fast && !mg_fast_eligible(v)) {
     k.fast = 0;
@@ -1138,10 +1147,87 @@ int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t
     h->no_modifiers = false;
     h->fused_w1 = false;  // (the one-wave build exists without modifiers only)
   }
+  return 0;
+}
+
+int mg_write_config_slot(mg_handle* h, int slot, const int32_t* cfg_blob, size_t cfg_words, void* stream) {
+  if (!h || !cfg_blob) return fail("mg_write_config_slot: NULL argument");
+  if (h->n_cfg_slots < 1) return fail("mg_write_config_slot: call mg_set_config_slots first");
+  if (slot < 0 || slot >= h->n_cfg_slots) return fail("mg_write_config_slot: slot out of range");
+  std::vector<int32_t> dcfg;
+  if (mg_task_stream(h, cfg_blob, cfg_words, "mg_write_config_slot", dcfg)) return 1;
+  KArgs& k = h->k;
+  if (mg_use_device(h)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (mg_upload(h, const_cast<int*>(k.gdc) + (size_t)slot * k.dc_stride, dcfg.data(), dcfg.size(), st)) return 1;
   if (h->maps_set) {
     std::vector<int> maps;
     for (size_t m = 0; m < h->host_map_cfg.size(); m++)
       if (h->host_map_cfg[m] == slot) maps.push_back((int)m);
+    if (mg_rebuild_templates(h, maps, st)) return 1;
+  }
+  return 0;
+}
+
+int mg_register_config(mg_handle* h, const int32_t* cfg_blob, size_t cfg_words, int32_t* config_id) {
+  if (!h || !cfg_blob || !config_id) return fail("mg_register_config: NULL argument");
+  if (h->n_cfg_slots < 1) return fail("mg_register_config: call mg_set_config_slots first");
+  std::vector<int32_t> dcfg;
+  if (mg_task_stream(h, cfg_blob, cfg_words, "mg_register_config", dcfg)) return 1;
+  if (mg_use_device(h)) return 1;
+  const size_t stride = (size_t)h->k.dc_stride;
+  if (h->reg_n == h->reg_cap) {  // grow the registry (rare, synchronous: steps in flight may be reading the old one)
+    const int cap = h->reg_cap ? 2 * h->reg_cap : 16;
+    int* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)cap * stride * 4));
+    HIPCHK(hipDeviceSynchronize());
+    if (h->reg_n) HIPCHK(hipMemcpy(d, h->d_reg, (size_t)h->reg_n * stride * 4, hipMemcpyDeviceToDevice));
+    if (h->d_reg) {
+      for (auto& p : h->allocs)
+        if (p == (void*)h->d_reg) p = d;
+      HIPCHK(hipFree(h->d_reg));
+    } else {
+      h->allocs.push_back(d);
+    }
+    h->d_reg = d;
+    h->reg_cap = cap;
+  }
+  HIPCHK(hipMemcpy(h->d_reg + (size_t)h->reg_n * stride, dcfg.data(), stride * 4, hipMemcpyHostToDevice));
+  *config_id = h->reg_n++;
+  return 0;
+}
+
+int mg_write_config_slots(mg_handle* h, int n, const int32_t* slots, const int32_t* config_ids, void* stream) {
+  if (!h || (n > 0 && (!slots || !config_ids))) return fail("mg_write_config_slots: NULL argument");
+  if (h->n_cfg_slots < 1) return fail("mg_write_config_slots: call mg_set_config_slots first");
+  if (n <= 0) return 0;
+  if (n > h->n_cfg_slots) return fail("mg_write_config_slots: more writes than slots");
+  for (int i = 0; i < n; i++) {
+    if (slots[i] < 0 || slots[i] >= h->n_cfg_slots) return fail("mg_write_config_slots: slot out of range");
+    if (config_ids[i] < 0 || config_ids[i] >= h->reg_n) return fail("mg_write_config_slots: unknown configuration id (mg_register_config)");
+  }
+  if (mg_use_device(h)) return 1;
+  hipStream_t st = (hipStream_t)stream;
+  KArgs& k = h->k;
+  if (!h->d_wlist && dalloc(h, &h->d_wlist, 2 * (size_t)h->n_cfg_slots)) return 1;
+  // (slots, ids) go up through the pinned ring in pieces of one ring slot; every piece is one copy kernel
+  const int piece = (int)std::max<size_t>(64, h->ring_words ? h->ring_words / 2 : (size_t)k.dc_stride / 2);
+  std::vector<int32_t> both;
+  for (int lo = 0; lo < n; lo += piece) {
+    const int m = std::min(piece, n - lo);
+    both.assign(slots + lo, slots + lo + m);
+    both.insert(both.end(), config_ids + lo, config_ids + lo + m);
+    int* d = h->d_wlist + 2 * (size_t)lo;
+    if (mg_upload(h, d, both.data(), both.size(), st)) return 1;
+    hipLaunchKernelGGL(mg_copy_config_kernel, dim3((unsigned)m), dim3(256), 0, st, const_cast<int*>(k.gdc), h->d_reg, d, d + m, k.dc_stride);
+  }
+  HIPCHK(hipGetLastError());
+  if (h->maps_set) {
+    std::vector<char> hit((size_t)h->n_cfg_slots, 0);
+    for (int i = 0; i < n; i++) hit[(size_t)slots[i]] = 1;
+    std::vector<int> maps;
+    for (size_t m = 0; m < h->host_map_cfg.size(); m++)
+      if (hit[(size_t)h->host_map_cfg[m]]) maps.push_back((int)m);
     if (mg_rebuild_templates(h, maps, st)) return 1;
   }
   return 0;

@@ -56,6 +56,8 @@ SYMBOLS = {
     "mg_set_config_slots": (ct.c_int, [_vp, ct.c_int, ct.c_int]),
     "mg_write_config_slot": (ct.c_int, [_vp, ct.c_int, _i32p, ct.c_size_t, _vp]),
     "mg_assign_map_configs": (ct.c_int, [_vp, ct.c_int, _i32p, _i32p, _vp]),
+    "mg_register_config": (ct.c_int, [_vp, _i32p, ct.c_size_t, _i32p]),
+    "mg_write_config_slots": (ct.c_int, [_vp, ct.c_int, _i32p, _i32p, _vp]),
     "mg_set_generated_maps": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _i32p, _i32p, ct.c_int, ct.c_uint64]),
     "mg_refresh_maps": (ct.c_int, [_vp, ct.c_int, _vp]),
     "mg_get_map": (ct.c_int, [_vp, ct.c_int, _u8p, _vp]),

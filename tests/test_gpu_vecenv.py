@@ -328,8 +328,8 @@ def test_set_maps_again_requires_full_reset():
 def test_episode_infos_equal_the_reference_stats_tracker(case_name, stats_every):
     """tests/golden/episode_infos.json (oracle/gen_golden_infos.py): the `infos` dict the reference's StatsTracker built at
     episode end (python/src/mettagrid/envs/stats_tracker.py:26-107).  Key for key, value for value; excluded, because they
-    are wall-clock readings: `attributes.completion_time` (presence checked) and the `timing_*` sections (not produced:
-    there is no per-env Python to time)."""
+    are wall-clock readings: `attributes.completion_time` (presence checked) and the values of the `timing_*` sections,
+    whose KEY SETS must equal the reference's (stats_tracker.py:109-140 over the timers of simulator.py:67-160)."""
     import json
     from pathlib import Path
 
@@ -354,6 +354,11 @@ def test_episode_infos_equal_the_reference_stats_tracker(case_name, stats_every)
     got.extend(v.recv()[5])
     got.extend(v.flush_infos())
     ours, ref = got[0], case["infos"]
+    assert set(ours["timing_per_epoch"]) == set(case["timing_per_epoch_keys"])
+    assert set(ours["timing_cumulative"]) == set(case["timing_cumulative_keys"])
+    assert all(isinstance(x, float) and x >= 0 for sect in ("timing_per_epoch", "timing_cumulative") for x in map(float, ours[sect].values()))
+    assert ours["timing_per_epoch"]["msec/sim.step"] > 0 and ours["timing_per_epoch"]["msec/sim.step.c_sim"] > 0
+    ours = {k: v for k, v in ours.items() if not k.startswith("timing_")}
     assert set(ours) == set(ref), (sorted(ours), sorted(ref))
     assert set(ours["game"]) == set(ref["game"]) and set(ours["agent"]) == set(ref["agent"])
     for sect in ("game", "agent", "per_label_rewards", "per_label_chest_deposits"):
