@@ -246,6 +246,19 @@ int mg_env_table(mg_handle* h, uint32_t* out, void* stream);
  * (reference: `get_episode_rewards`, mettagrid_c.cpp:928-930, read by StatsTracker.on_episode_end). */
 int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, void* stream);
 
+/* The episodes that finished between two readings of the finished-episode counter (status word 1, mg_status_buffer),
+ * in the order they ended: env_ids[i], map_ids[i] = the environment and the map slot it played, for
+ * i < to_count - from_count.  The device keeps the last mg_finished_ring_capacity() entries (>= 16 x num_envs, >= 1024;
+ * a larger span is an error: read the newest `capacity` entries and count the rest as lost).  Steps still queued while the
+ * copy runs append behind `to_count`; they reach the entries being read only after capacity - (to_count - from_count)
+ * more episodes.  This replaces a scan over every
+ * environment's episode counter (the reference learns of an episode's end from the step call that ends it,
+ * mettagrid_puffer_env.py:158-183; here the host polls).  Entries below a counter value the host has read are complete,
+ * so the copy runs on `stream` and waits for nothing else: give it a stream of its own, beside the one the steps are
+ * queued on (the legacy default stream would make it wait for all of them). */
+int mg_finished_ring_capacity(mg_handle* h);
+int mg_finished_ring(mg_handle* h, uint32_t from_count, uint32_t to_count, int32_t* env_ids, int32_t* map_ids, void* stream);
+
 /* The same for n environments at once (what `StatsTracker.on_episode_end`, envs/stats_tracker.py:26-107, reads per episode:
  * `get_episode_stats()` + `get_episode_rewards()` of the episode that has just ended): agent_values / agent_touched
  * [n][A][SA], game_values / game_touched [n][SG], rewards [n][A], steps [n], host arrays.  One gather launch and one

@@ -385,7 +385,21 @@ class MettaGridBatch:
         self._check(self.L.mg_finished_rewards(self._h, env, _p(r, ct.c_float), ct.byref(steps), self._stream()))
         return r, int(steps.value)
 
-    def finished_batch(self, env_ids: Sequence[int]):
+    def finished_ring_capacity(self) -> int:
+        return int(self.L.mg_finished_ring_capacity(self._h))
+
+    def finished_ring(self, from_count: int, to_count: int, stream=None):
+        """(env ids, map slots) of the episodes that finished between two readings of the finished-episode counter, in the
+        order they ended (`mg_finished_ring`; no stream synchronisation)."""
+        n = (int(to_count) - int(from_count)) & 0xFFFFFFFF
+        envs, maps = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        if n:
+            self._check(self.L.mg_finished_ring(self._h, int(from_count) & 0xFFFFFFFF, int(to_count) & 0xFFFFFFFF,
+                                                _p(envs, ct.c_int32), _p(maps, ct.c_int32),
+                                                self._stream() if stream is None else ct.c_void_p(int(stream))))  # fmt: skip
+        return envs, maps
+
+    def finished_batch(self, env_ids: Sequence[int], stream=None):
         """The last finished episode of several environments in one device round trip: (agent_values [n, A, SA],
         agent_touched [n, A, SA] bool, game_values [n, SG], game_touched [n, SG] bool, episode_rewards [n, A], steps [n])."""
         ids = np.ascontiguousarray(env_ids, dtype=np.int32)
@@ -398,7 +412,8 @@ class MettaGridBatch:
             self._check(
                 self.L.mg_finished_batch(
                     self._h, n, _p(ids, ct.c_int32), _p(av, ct.c_float), _p(at, ct.c_uint8), _p(gv, ct.c_float),
-                    _p(gt, ct.c_uint8), _p(rew, ct.c_float), _p(steps, ct.c_uint32), self._stream(),
+                    _p(gt, ct.c_uint8), _p(rew, ct.c_float), _p(steps, ct.c_uint32),
+                    self._stream() if stream is None else ct.c_void_p(int(stream)),
                 )
             )  # fmt: skip
         return av, at.astype(bool), gv, gt.astype(bool), rew, steps

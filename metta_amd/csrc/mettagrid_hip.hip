@@ -405,6 +405,12 @@ int mg_create(const int32_t* cfg_blob, size_t cfg_words, int num_envs, int devic
   if (dalloc(h.get(), &k.fin_steps, (size_t)num_envs)) return 1;
   if (dalloc(h.get(), &k.summary, (size_t)(3 + k.SG))) return 1;
   if (dalloc(h.get(), &k.status, 4)) return 1;
+  {
+    uint32_t cap = 1024;  // (8 B an entry)
+    while (cap < 16u * (uint32_t)num_envs) cap <<= 1;
+    if (dalloc(h.get(), &k.fin_ring, (size_t)cap)) return 1;
+    k.fin_ring_mask = cap - 1u;
+  }
   if (dalloc(h.get(), &k.obs, N * c.T * 3)) return 1;
   if (dalloc(h.get(), &k.rewards, N)) return 1;
   if (dalloc(h.get(), &k.term, N)) return 1;
@@ -1765,6 +1771,29 @@ int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, 
 // The last finished episode of several environments at once: one gather launch and one device -> host copy per chunk of
 // environments instead of six blocking copies per environment (mg_episode_stats(last_finished) + mg_finished_rewards).
 #define MG_FIN_CHUNK 256
+int mg_finished_ring_capacity(mg_handle* h) { return h ? (int)(h->k.fin_ring_mask + 1u) : 0; }
+
+int mg_finished_ring(mg_handle* h, uint32_t from_count, uint32_t to_count, int32_t* env_ids, int32_t* map_ids, void* stream) {
+  if (!h || !env_ids || !map_ids) return fail("mg_finished_ring: NULL argument");
+  const uint32_t n = to_count - from_count, cap = h->k.fin_ring_mask + 1u;
+  if (n == 0) return 0;
+  if (n > cap) return fail("mg_finished_ring: " + std::to_string(n) + " episodes finished since the last read, the ring holds " +
+                           std::to_string(cap) + " (the host fell behind)");
+  if (mg_use_device(h)) return 1;
+  std::vector<uint2> buf((size_t)n);
+  const uint32_t lo = from_count & h->k.fin_ring_mask, first = std::min(n, cap - lo);
+  // (entries up to a counter value the host has SEEN were written by kernels that finished before that value was copied)
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(buf.data(), h->k.fin_ring + lo, (size_t)first * sizeof(uint2), hipMemcpyDeviceToHost, st));
+  if (first < n) HIPCHK(hipMemcpyAsync(buf.data() + first, h->k.fin_ring, (size_t)(n - first) * sizeof(uint2), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (uint32_t i = 0; i < n; i++) {
+    env_ids[i] = (int32_t)buf[i].x;
+    map_ids[i] = (int32_t)buf[i].y;
+  }
+  return 0;
+}
+
 int mg_finished_batch(mg_handle* h, int n, const int32_t* env_ids, float* agent_values, uint8_t* agent_touched, float* game_values,
                       uint8_t* game_touched, float* rewards, uint32_t* steps, void* stream) {
   if (!h || (n > 0 && (!env_ids || !agent_values || !agent_touched || !game_values || !game_touched || !rewards || !steps)))

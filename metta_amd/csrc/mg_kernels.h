@@ -78,6 +78,11 @@ struct KArgs {
   uint32_t* fin_steps;    // [E]
   double* summary;        // [3 + SG]
   uint32_t* status;       // [4]: OR of every env's error bits | finished episodes (count) | 2 spare words
+  // Finished episodes in the order they ended: entry (count & mask) = (environment, map slot of the finished episode),
+  // written when the environment restarts.  The host reads the entries between two values of the counter
+  // (mg_finished_ring) instead of scanning every environment's episode counter.
+  uint2* fin_ring;
+  uint32_t fin_ring_mask;
   uint8_t* obs;
   float* rewards;
   uint8_t* term;
@@ -1166,7 +1171,7 @@ __device__ inline void mg_copy(void* __restrict__ dst, const void* __restrict__ 
 }
 
 // Keep the finished episode's stats for the host and add it to the device-wide summary.
-__device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t steps, int tid, int nt) {
+__device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t steps, uint32_t map_id, int tid, int nt) {
   size_t na = (size_t)a.A * a.SA, nta = (size_t)a.A * a.TW;
   float* fas = a.fin_astats + (size_t)e * na;
   mg_copy(fas, a.astats + (size_t)e * na, na * 4, tid, nt);
@@ -1204,7 +1209,8 @@ __device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t step
   }
   if (tid == 0) {
     a.fin_steps[e] = steps;
-    atomicAdd(&a.status[1], 1u);
+    const uint32_t idx = atomicAdd(&a.status[1], 1u);
+    if (a.fin_ring) a.fin_ring[idx & a.fin_ring_mask] = make_uint2((uint32_t)e, map_id);
     atomicAdd(&a.summary[0], 1.0);
     atomicAdd(&a.summary[1], (double)steps);
   }
@@ -1332,7 +1338,7 @@ __device__ inline void mg_clipper_init(const KArgs& a, const int* dc, DAsm* as, 
 // Restart a finished environment from the per-map templates (MettaGridPufferEnv.step -> _new_sim(),
 // mettagrid_puffer_env.py:158-164; same seed, next map).  All threads of the workgroup; HBM state only.
 __device__ inline void mg_restart_env(const KArgs& a, int e, DEnv& env, int tid, int nt) {
-  mg_snapshot_finished(a, e, env.step, tid, nt);
+  mg_snapshot_finished(a, e, env.step, env.map_id, tid, nt);
   __syncthreads();
   const int m = (int)(((int)env.map_id + a.map_stride) % a.P);
   env.map_id = (uint32_t)m;

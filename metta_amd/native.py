@@ -56,6 +56,8 @@ SYMBOLS = {
     "mg_set_config_slots": (ct.c_int, [_vp, ct.c_int, ct.c_int]),
     "mg_write_config_slot": (ct.c_int, [_vp, ct.c_int, _i32p, ct.c_size_t, _vp]),
     "mg_assign_map_configs": (ct.c_int, [_vp, ct.c_int, _i32p, _i32p, _vp]),
+    "mg_finished_ring_capacity": (ct.c_int, [_vp]),
+    "mg_finished_ring": (ct.c_int, [_vp, ct.c_uint32, ct.c_uint32, _i32p, _i32p, _vp]),
     "mg_register_config": (ct.c_int, [_vp, _i32p, ct.c_size_t, _i32p]),
     "mg_write_config_slots": (ct.c_int, [_vp, ct.c_int, _i32p, _i32p, _vp]),
     "mg_set_generated_maps": (ct.c_int, [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _i32p, _i32p, _i32p, _i32p, ct.c_int, ct.c_uint64]),

@@ -495,3 +495,48 @@ def test_async_send_keeps_the_action_tensor_alive_for_the_side_stream():
     torch.cuda.synchronize()
     env.close()
     twin.close()
+
+
+@pytest.mark.parametrize("collect_every,ring_cap", [(1, None), (25, None), (25, 16)])
+def test_finished_ring_reports_every_episode_and_counts_overwritten_ones(collect_every, ring_cap):
+    """The device's ring of finished episodes (`mg_finished_ring`): between two collections the host reads which
+    environments finished, in order.  Collected often enough every episode is reported; when an environment finishes twice
+    between collections only its last episode's statistics survive on the device -- the earlier one is counted in
+    `episodes_dropped`, never reported twice and never silently lost.  The sections of an info are decoded
+    lazily and behave as plain dicts."""
+    import json as _json
+
+    from metta_amd.vecenv import MettaGridDeviceVecEnv
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 6
+    pool = load_map_pool()[:4]
+    E, A = 16, 24
+    v = MettaGridDeviceVecEnv(cfg, E, maps=pool, device=0, seed=1, early_reset=True)
+    v.collect_every = collect_every
+    if ring_cap:  # as if the device's ring were this short: a host that fell behind reads its newest entries only
+        v._ring_cap = ring_cap
+    v.async_reset(1)
+    c0 = int(v.batch.status_tensor()[1].item())
+    rs = np.random.RandomState(0)
+    infos = []
+    for _ in range(80):
+        infos.extend(v.recv()[5])
+        v.send(rs.randint(0, 5, size=E * A).astype(np.int32))
+    infos.extend(v.recv()[5])
+    infos.extend(v.flush_infos())
+    total = int(v.batch.status_tensor()[1].item()) - c0
+    eps = [i for i in infos if "attributes" in i]
+    assert total >= E * 10
+    assert len(eps) + v.episodes_dropped == total, (len(eps), v.episodes_dropped, total)
+    if collect_every == 1:
+        assert v.episodes_dropped == 0
+    else:
+        assert v.episodes_dropped > 0
+    one = eps[-1]
+    assert isinstance(one["game"], dict) and isinstance(one["agent"], dict)
+    assert "tokens_written" in one["game"] and one["game"]["tokens_written"] > 0
+    assert set(one["agent"]) >= {"action.move.success"} or set(one["agent"]) >= {"action.noop.success"}
+    assert _json.loads(_json.dumps(one["game"])) == dict(one["game"])  # serialises like the dict it is
+    assert one["attributes"]["steps"] <= 6 and one["attributes"]["max_steps"] == 6
+    v.close()
