@@ -668,19 +668,39 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
     `task_maps=True`: the task's own `game.map_builder` builds the map of its episode on the host, as the reference's
     simulator does at every episode start (simulator.py:264-267), and `mg_write_map_slot` puts it into the idle slot
     together with the configuration -- for curricula that bucket over map parameters (object counts, terrain).  The
-    maps must have the size of the first task's; a task whose map does not fit is redrawn like any invalid task."""
+    maps must have the size of the first task's; a task whose map does not fit is redrawn like any invalid task.
+
+    `lag=0`: the reference's order exactly, for a curriculum shared by the environments of a serial vecenv.  Every step
+    is followed by a look at the terminal flags (one synchronisation per step, `stats_every = 1`); the environments that
+    finished are visited in ascending order, each one `complete` -> `update_task_performance` -> `get_task`
+    (curriculum_env.py:105-117), and the task drawn goes into the twin slot, the one this very environment plays from
+    the next step on -- the slot write is queued before that step, so the environment waits for it as the reference's
+    waits for `set_mg_config`.  The draws before the first step are the reference's too: two per environment when the
+    vecenv is made (metta/rl/vecenv.py:45 and curriculum_env.py:32) and none in a reset -- the wrapper's `reset` (:65-94)
+    is shadowed by its own `__getattribute__` (:158-186, "reset" is not among the names it keeps), so the first episode
+    plays the configuration of an environment's first draw and is reported to the task of its second.  Pinned against
+    the reference's `CurriculumEnv` by tests/golden/curriculum_env.json."""
 
     def __init__(self, curriculum, num_envs: int, maps: Optional[Sequence] = None, num_maps: int = 64, device: int = 0,
                  seed: int = 0, early_reset: bool = False, map_seed: int = 0, init_obs_passes: int = 2,
-                 device_maps: bool = False, map_refresh_every: Optional[int] = None, task_maps: bool = False):  # fmt: skip
+                 device_maps: bool = False, map_refresh_every: Optional[int] = None, task_maps: bool = False,
+                 lag: int = 1):  # fmt: skip
         if task_maps and device_maps:
             raise APIUsageError("task_maps builds maps on the host; device_maps draws them on the device: choose one")
+        if lag not in (0, 1):
+            raise APIUsageError("lag is 0 (the reference's order, one synchronisation per step) or 1 (twin slots written ahead)")
+        self._lag = int(lag)
         self._task_maps = bool(task_maps)
         self._map_rng = np.random.default_rng(map_seed + 1)
         self._curriculum = curriculum
         self._current_task = curriculum.get_task()  # (the reference draws one in its constructor too, :32)
         cfg = self._current_task.get_env_cfg()
         E = int(num_envs)
+        # lag 0: (task whose configuration environment e plays next, task its result is reported to)
+        self._env_next: list = []
+        if self._lag == 0:
+            drawn = [self._current_task] + [curriculum.get_task() for _ in range(2 * E - 1)]
+            self._env_next = [(drawn[2 * e], drawn[2 * e + 1]) for e in range(E)]
         if not device_maps:
             if maps is None:
                 rng = np.random.default_rng(map_seed)
@@ -691,7 +711,8 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
                          config_slots=2 * E)  # fmt: skip
         self.batch.set_auto_reset(True, E)
         self.batch.assign_map_configs(np.arange(2 * E), np.arange(2 * E))
-        self._slot_task: list = [None] * (2 * E)
+        self._slot_task: list = [None] * (2 * E)  # the task an episode on this slot is reported to
+        self._slot_cfg: list = [None] * (2 * E)   # the task whose configuration the slot holds (lag 0: may differ, once)
         self._blob_cache: dict = {}
         self._cfg_ids: dict = {}         # task id -> configuration id in the handle's registry (mg_register_config)
         self._pending: list = []         # (slot, configuration id) written by the next flush: one library call per poll
@@ -700,6 +721,8 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
         self._stats_update_frequency = 50  # curriculum_env.py:36
         self._first_reset_done = False
         self.tasks_completed = 0
+        if self._lag == 0:
+            self.stats_every = 1
 
     def _write_task(self, slot: int, task) -> None:
         key = getattr(task, "_task_id", None)
@@ -712,7 +735,7 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
                 cid = self.batch.register_config(compile_game(task.get_env_cfg(), init_obs_passes=self.batch._init_obs_passes))
                 self._cfg_ids[key] = cid
             self._pending.append((slot, cid))
-            self._slot_task[slot] = task
+            self._slot_task[slot] = self._slot_cfg[slot] = task
             return
         comp = self._blob_cache.get(key) if key is not None else None
         if comp is None:
@@ -725,7 +748,7 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
             self.batch.write_map_slot(slot, task.get_env_cfg().game.map_builder.build(self._map_rng))
             self.__dict__.setdefault("_groups_cache", {}).pop(slot, None)
         self.batch.write_config_slot(slot, comp)
-        self._slot_task[slot] = task
+        self._slot_task[slot] = self._slot_cfg[slot] = task
 
     def _new_task(self, slot: int) -> None:
         # curriculum_env.py:111-126: up to ten attempts at a task whose configuration is valid
@@ -759,8 +782,13 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
             self._new_task(map_slot)
 
     def async_reset(self, seed: Optional[int] = None) -> None:
-        for slot in range(2 * self.num_environments):
-            self._new_task(slot)
+        if self._lag:  # both slots of every environment get a task
+            for slot in range(2 * self.num_environments):
+                self._new_task(slot)
+        else:  # no draw: every environment starts over with the configuration it would have played next
+            for e, (plays, reported) in enumerate(self._env_next):
+                self._write_task(e, plays)
+                self._slot_task[e] = reported
         self._flush_writes()
         self._current_task = self._slot_task[0]
         super().async_reset(seed)
@@ -777,7 +805,7 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
             self._stats_update_counter = 0
 
     def _slot_max_steps(self, map_slot: int) -> int:
-        task = self._slot_task[map_slot]
+        task = self._slot_cfg[map_slot]
         return int(task.get_env_cfg().game.max_steps) if task is not None else int(self.cfg.game.max_steps)
 
     def _episode_finished(self, env: int, map_slot: int, mean_reward: float, info: dict, current_slot: int = -1) -> None:
@@ -786,6 +814,13 @@ class CurriculumDeviceVecEnv(MettaGridDeviceVecEnv):
             task.complete(mean_reward)
             self._curriculum.update_task_performance(task._task_id, mean_reward)
             self.tasks_completed += 1
+        if self._lag == 0:
+            if self.stats_every != 1:
+                raise APIUsageError("lag=0 needs stats_every = 1: the task of the next episode is drawn on the step that ends this one")
+            twin = (map_slot + self.num_environments) % (2 * self.num_environments)
+            self._new_task(twin)
+            self._env_next[env] = (self._slot_cfg[twin], self._slot_task[twin])
+            return
         if current_slot == map_slot:
             return  # (a host that fell a whole episode behind: the environment is back on this slot; leave it)
         self._new_task(map_slot)

@@ -380,3 +380,59 @@ def test_task_with_limit_modifiers_keeps_the_modifier_build_across_new_pools():
     _compare_state(b, oras, 69)
     b.check_errors()
     b.close()
+
+
+def test_lag0_curriculum_equals_the_reference_curriculum_env():
+    """tests/golden/curriculum_env.json (oracle/gen_golden_curriculum.py): the reference's own `CurriculumEnv`
+    (curriculum_env.py:10-142) over its `Simulator` + `StatsTracker`, three environments of a serial vecenv sharing one
+    curriculum whose choices depend on the order of everything it is told.  `lag=0` must reproduce the curriculum's call
+    log entry for entry (`get` / `complete` / `update`, task ids exact, rewards to 1e-6), play the same task in every
+    episode of every environment, and end every episode on the same step with the same rewards and observations."""
+    import json
+    from pathlib import Path
+
+    from metta_amd.vecenv import CurriculumDeviceVecEnv
+    from oracle.gen_golden import digest
+    from oracle.gen_golden_curriculum import StubCurriculum, apply_recipe
+
+    fx = json.loads((Path(__file__).resolve().parent / "golden" / "curriculum_env.json").read_text())
+    E, A, steps = fx["num_envs"], fx["num_agents"], fx["steps"]
+    cfgs = [apply_recipe(make_arena(A), tuple(r)) for r in fx["recipes"]]
+    grid = np.array(fx["cell_names"])[np.array(fx["map_codes"], np.uint8).reshape(fx["map_shape"])]
+    cur = StubCurriculum(cfgs, fx["threshold"])
+    env = CurriculumDeviceVecEnv(cur, E, maps=[grid], device=0, seed=fx["seed"], lag=0)
+    env.async_reset(fx["seed"])
+    assert cur.draws == fx["draws_before_stepping"]
+    assert [env._slot_task[e]._task_id for e in range(E)] == fx["first_playing"]
+    first = [next(ep for ep in fx["episodes"] if ep["env"] == e) for e in range(E)]
+    assert any(ep["played"] != ep["task"] for ep in first), "the fixture holds the reference's first-episode quirk"
+    actions = np.array(fx["actions"], np.int32).reshape(steps, E * A)
+    want = {(ep["env"], ep["step"]): ep for ep in fx["episodes"]}
+    infos, seen = list(env.recv()[5]), 0
+    for t in range(steps):
+        env.send(actions[t])
+        o, r, d, tr, ta, info, ids, mask = env.recv()
+        infos += info
+        done = (d.view(E, A).all(dim=1) | tr.view(E, A).all(dim=1)).cpu().numpy()
+        obs = o.cpu().numpy().reshape(E, A, -1, 3)
+        for e in range(E):
+            assert bool(done[e]) == ((e, t) in want), f"step {t} env {e}: episode end"
+            if done[e]:
+                assert digest(obs[e]) == want[(e, t)]["obs_digest"], f"step {t} env {e}: last observations"
+                seen += 1
+    assert seen == len(fx["episodes"]) >= 40
+    assert len(cur.log) == len(fx["log"])
+    for i, (a, b) in enumerate(zip(cur.log, fx["log"])):
+        assert a[:2] == b[:2], f"call {i}: {a} vs {b}"
+        if len(b) == 3:
+            assert a[2] == pytest.approx(b[2], rel=0, abs=1e-6), f"call {i}: {a} vs {b}"
+    eps = [i for i in infos if "attributes" in i]
+    assert len(eps) == len(fx["episodes"])
+    for got, ep in zip(eps, fx["episodes"]):  # reported in the reference's order: by step, environments ascending
+        assert got["attributes"]["steps"] == ep["steps"] and got["attributes"]["seed"] == fx["seed"] + ep["env"]
+        assert got["attributes"]["max_steps"] == fx["recipes"][ep["played"]][0]
+        # (`env_curriculum/*` rides on an info every 50 steps -- of each wrapper there, of the vecenv here)
+        assert set(got) >= {k for k in ep["info_keys"] if not k.startswith("env_curriculum/")}
+        assert got["agent"].get("action.move.success", 0.0) == pytest.approx(ep["agent_move_success"], rel=1e-6)
+        assert got["per_label_rewards"][cfgs[0].label] == pytest.approx(ep["mean_reward"], rel=0, abs=1e-6)
+    env.close()

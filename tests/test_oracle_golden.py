@@ -220,3 +220,47 @@ def test_invalid_action_ids_make_the_reference_keys():
     folded = o0.pop("action.invalid_index.other", 0.0)
     assert all(r0[k] == v for k, v in o0.items())
     assert folded == sum(v for k, v in r0.items() if k not in o0)
+
+
+def test_oracle_plays_the_reference_curriculum_fixture():
+    """tests/golden/curriculum_env.json (the reference's `CurriculumEnv`, oracle/gen_golden_curriculum.py): the oracle,
+    driven in the wrapper's order (curriculum_env.py:103-117: `complete` -> `update_task_performance` -> `get_task`, the
+    drawn configuration played from the next step on), reproduces the curriculum's call log, every episode's end step,
+    rewards and last observations -- configurations with stat rewards, inventory rewards and initial inventories."""
+    import json
+    from pathlib import Path
+
+    from oracle.gen_golden_curriculum import StubCurriculum, apply_recipe
+
+    fx = json.loads((Path(__file__).resolve().parent / "golden" / "curriculum_env.json").read_text())
+    E, A, steps = fx["num_envs"], fx["num_agents"], fx["steps"]
+    cfgs = [apply_recipe(make_arena(A), tuple(r)) for r in fx["recipes"]]
+    comps = {id(c): compile_game(c, init_obs_passes=2) for c in cfgs}
+    grid = np.array(fx["cell_names"])[np.array(fx["map_codes"], np.uint8).reshape(fx["map_shape"])]
+    cells = comps[id(cfgs[0])].encode_map(grid)
+    cur = StubCurriculum(cfgs, fx["threshold"])
+    drawn = [cur.get_task() for _ in range(2 * E)]  # metta/rl/vecenv.py:45 and curriculum_env.py:32, per environment
+    plays, reported = [drawn[2 * e].get_env_cfg() for e in range(E)], [drawn[2 * e + 1] for e in range(E)]
+    envs = [make_oracle_env(comps[id(plays[e])], cells, fx["seed"] + e) for e in range(E)]
+    actions = np.array(fx["actions"], np.int32).reshape(steps, E, A)
+    want = {(ep["env"], ep["step"]): ep for ep in fx["episodes"]}
+    seen = 0
+    for t in range(steps):
+        for e in range(E):
+            if envs[e].terminals.all() or envs[e].truncations.all():
+                envs[e] = make_oracle_env(comps[id(plays[e])], cells, fx["seed"] + e)
+            envs[e].step(actions[t, e])
+            done = bool(envs[e].terminals.all() or envs[e].truncations.all())
+            assert done == ((e, t) in want), f"step {t} env {e}"
+            if done:
+                ep = want[(e, t)]
+                assert digest(envs[e].obs) == ep["obs_digest"]
+                assert np.array_equal(np.asarray(envs[e].episode_rewards, np.float32), np.asarray(ep["rewards"], np.float32))
+                mean = np.asarray(envs[e].episode_rewards, np.float32).mean()
+                reported[e].complete(mean)
+                cur.update_task_performance(reported[e]._task_id, mean)
+                reported[e] = cur.get_task()
+                plays[e] = reported[e].get_env_cfg()
+                seen += 1
+    assert seen == len(fx["episodes"])
+    assert cur.log == fx["log"]
