@@ -55,6 +55,7 @@ sys.path.insert(0, str(ROOT))
 ENVS_PER_GPU = 4096
 AGENTS = 24
 ALGO_BYTES_PER_AGENT_STEP = 1035.0  # 610 B boundary + ~425 B state (arena)
+BOUNDARY_BYTES_PER_AGENT_STEP = 610.0  # 600 B observations + actions, rewards, flags
 OBS_BYTES_PER_AGENT_STEP = 970.0  # the observation kernel alone, 600 B written + ~370 B read
 PROFILE_STRIDE = 8  # steps between HIP-event brackets in the timed region
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
@@ -181,13 +182,112 @@ def cpu_baseline(budget_s: float = 10.0) -> dict:
 
 
 # ----------------------------------------------------------------------------------------------------------
+def rollout_workload(args, wl, rank, local_rank, world, use_dist, saved_stdout, pool, E, G) -> None:
+    """`--workload rollout` (BASELINE configs[4] on the same shards): recv -> LSTM policy forward (bf16) -> sampling ->
+    send, device-resident (metta_amd/rollout.py; reference `CoreTrainingLoop.rollout_phase`, metta/rl/training/core.py:
+    67-189), G asynchronous groups of environments per rank as the reference's async_factor; the finished-episode summary
+    is all-reduced every 128 steps like the other workloads.  A step = every environment of the rank stepped once."""
+    import torch
+    import torch.distributed as dist
+
+    from metta_amd.rollout import LSTMPolicy
+    from metta_amd.vecenv import AsyncDeviceVecEnv, MettaGridDeviceVecEnv
+
+    dev = torch.device("cuda", local_rank)
+    A, cfg = wl["agents"], wl["cfg"]
+    seed0 = rank * E  # global environment ids: rank r owns [r*E, (r+1)*E), environment g has seed g (bench_shard)
+    if G > 1:
+        env = AsyncDeviceVecEnv(cfg, E, E // G, device=local_rank, seed=seed0, maps=pool, early_reset=True)
+        handles = [g.batch for g in env.groups]
+    else:
+        env = MettaGridDeviceVecEnv(cfg, E, maps=pool, device=local_rank, seed=seed0, early_reset=True)
+        handles = [env.batch]
+    env.async_reset(seed0)  # (stats_every = 0: finished episodes are collected without blocking a send)
+    n_group = env.agents_per_batch if G > 1 else env.num_agents
+    pol = LSTMPolicy(cfg.game.obs.num_tokens, env.single_action_space.n).to(dev).to(torch.bfloat16)
+    states = [pol.initial_state(n_group, dev, torch.bfloat16) for _ in range(G)]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    summary = torch.zeros(3 + len(handles[0].compiled.game_slot_names), dtype=torch.float64, device=dev)
+    accs = [h.summary_tensor() for h in handles]
+
+    def reduce_summary():
+        s = torch.stack(accs).sum(0)
+        for a in accs:
+            a.zero_()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        summary.add_(s)
+
+    @torch.no_grad()
+    def run(k: int, base: int):
+        for t in range(k):
+            for q in range(G):  # one step of the rank = every group once
+                o, r, d, tr, ta, infos, ids, mask = env.recv()
+                logits, value, st = pol(o, states[q])
+                done = (d | tr).to(st[0].dtype).unsqueeze(1)
+                states[q] = (st[0] * (1 - done), st[1] * (1 - done))
+                acts = torch.multinomial(torch.softmax(logits.float(), dim=-1), 1, generator=gen).squeeze(1).to(torch.int32)
+                env.send(acts)
+            if use_dist and (base + t) % 128 == 127:
+                reduce_summary()
+
+    def sync_all():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(args.warmup, 0)
+    env.flush_infos()
+    if use_dist:
+        reduce_summary()
+    sync_all()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
+    sync_all()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    sync_all()
+    dt = time.perf_counter() - t0
+    for h in handles:
+        h.check_errors()
+    step_path = handles[0].step_path()
+    env.close()
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max.item())
+    if rank == 0:
+        step_s = dt / args.steps
+        achieved = ALGO_BYTES_PER_AGENT_STEP * E * A / step_s / 1e9
+        print(json.dumps({
+            "metric": "agent-steps/sec (node), device-resident rollout with an LSTM policy @1/2/4/8 GPU (BASELINE configs[4]; not the headline metric)",
+            "value": float(world) * E * A * args.steps / dt, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 environment step, bf16 policy", "data": "synthetic",
+            "config": {"workload": f"{E} " + wl["describe"] + ", random-init policy, actions sampled on the device, auto-reset on",
+                       "envs_per_gpu": E, "agents_per_env": A, "groups": G, "parallelism": f"env-sharded x{world} (independent instances)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": step_path,
+                         "basis": "wall clock of the whole rollout step against the ENVIRONMENT path's algorithmic bytes: the policy's "
+                         "GEMMs and the u8 -> bf16 observation cast bound this workload (profiles/r03_rollout_kernel_stats.csv), "
+                         "so this is the env path's share, not a kernel roofline"},
+            "cpu_baseline": None,
+        }), flush=True)  # fmt: skip
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--envs", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--groups", type=int, default=4, help="independent environment groups, one HIP stream each (1 = one handle)")
+    ap.add_argument("--workload", choices=("arena", "combat", "rollout"), default="arena",
+                    help="arena = BASELINE configs[1] (the headline); combat = configs[3], rollout = configs[4]: the same sharding "
+                    "(bench_shard) and summary all-reduce, for the multi-GPU curves of those configurations")
+    ap.add_argument("--envs", type=int, default=None, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--groups", type=int, default=None, help="independent environment groups, one HIP stream each (1 = one handle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the one-handle comparison run (profiling passes: one launch shape only)")
     ap.add_argument("--no-obs-pass", action="store_true", help="skip the observation-kernel pass (metric 2) after the timed region")
@@ -201,16 +301,16 @@ def main() -> None:
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    arena = args.workload == "arena"
     cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and arena:
         cpu = cpu_baseline(args.cpu_seconds)
 
     import torch
     import torch.distributed as dist
 
     from metta_amd.batch import MettaGridBatch
-    from metta_amd.builder import make_arena
-    from metta_amd.dist import bench_shard
+    from metta_amd.dist import bench_shard, bench_workload
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -229,17 +329,21 @@ def main() -> None:
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    E, A = args.envs, AGENTS
-    G = args.groups if args.groups >= 1 and E % max(args.groups, 1) == 0 else 1
+    wl = bench_workload(args.workload)
+    E, A = args.envs or wl["envs"], wl["agents"]
+    groups = args.groups or wl["groups"]
+    G = groups if groups >= 1 and E % max(groups, 1) == 0 else 1
     n = E // G
-    cfg = make_arena(A)
-    pool = _load_pool()
+    cfg = wl["cfg"]
+    pool = wl["maps"] or _load_pool()
     seeds, map_ids = bench_shard(rank, E, len(pool))  # env g: seed g (pufferlib vector.py:90), map g mod pool
     # desynchronise episode phases like the reference's EarlyResetHandler (early_reset_handler.py:6-20)
-    early = np.random.RandomState(rank).randint(1, cfg.game.max_steps + 1, size=E).astype(np.uint32)
+    early = np.random.RandomState(rank).randint(1, max(int(cfg.game.max_steps), 1) + 1, size=E).astype(np.uint32)
     N = E * A
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    table = torch.randint(0, 5, (64, N), generator=g, device=dev, dtype=torch.int32)
+    table = torch.randint(0, wl["num_actions"], (64, N), generator=g, device=dev, dtype=torch.int32)
+    if args.workload == "rollout":
+        return rollout_workload(args, wl, rank, local_rank, world, use_dist, saved_stdout, pool, E, G)
 
     def make_batches(groups: int):
         m = E // groups
@@ -332,7 +436,7 @@ def main() -> None:
         b.close()
 
     single = None
-    if G > 1 and rank == 0 and not use_dist and not args.no_single:
+    if G > 1 and rank == 0 and not use_dist and not args.no_single and arena:
         # the same workload through one handle on one stream (what --groups 1 reports as the headline)
         one = make_batches(1)
         cur = [torch.cuda.current_stream(dev)]
@@ -360,7 +464,7 @@ def main() -> None:
         }
 
     obs_kernel = None
-    if rank == 0 and not args.no_obs_pass:
+    if rank == 0 and not args.no_obs_pass and arena:
         # BASELINE's second metric (SURVEY 8d metric 2): the observation kernel alone.  The fused step has no kernel
         # boundary around its encode, so the same environments are stepped by a handle that runs the step as three
         # launches (MG_NO_FUSED is read when the pool is set), with HIP events around mg_obs_kernel only.
@@ -406,22 +510,26 @@ def main() -> None:
         agent_steps = float(world) * E * A * args.steps
         value = agent_steps / dt
         step_s = dt / args.steps
-        algo_step = ALGO_BYTES_PER_AGENT_STEP * E * A  # one step of all the rank's environments
+        # (combat: the 610 B boundary only -- its grid and agent records live in HBM and their traffic is not in the
+        # figure, so `frac` is a lower bound there)
+        algo_agent = ALGO_BYTES_PER_AGENT_STEP if arena else BOUNDARY_BYTES_PER_AGENT_STEP
+        algo_step = algo_agent * E * A  # one step of all the rank's environments
         achieved = algo_step / step_s / 1e9  # from the wall clock of the timed region
         mean_kernel_s = float(kernel_ms.mean()) * 1e-3 if len(kernel_ms) else float("nan")
-        algo_bytes = ALGO_BYTES_PER_AGENT_STEP * n * A  # one launch = one group's step
+        algo_bytes = algo_agent * n * A  # one launch = one group's step
         per_launch = algo_bytes / mean_kernel_s / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
-                if tj.get("envs_per_launch", tj.get("envs")) == n:
+                if arena and tj.get("envs_per_launch", tj.get("envs")) == n:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "agent-steps/sec (node) arena 24-agent @1/2/4/8 GPU; obs-encode HBM GB/s",
+            "metric": "agent-steps/sec (node) arena 24-agent @1/2/4/8 GPU; obs-encode HBM GB/s" if arena
+            else "agent-steps/sec (node), combat stress 256x256x1024 @1/2/4/8 GPU (BASELINE configs[3]; not the headline metric)",
             "value": value,
             "unit": "agent-steps/s",
             "n_gpus": world,
@@ -434,8 +542,8 @@ def main() -> None:
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{E} arena envs x {A} agents per GPU (BASELINE configs[1]), uniform-random actions, "
-                "full 200-token observations, auto-reset on, 64 reference-generated 62x62 maps",
+                "workload": f"{E} " + wl["describe"] + ", uniform-random actions, full 200-token observations, auto-reset on, "
+                + ("64 reference-generated 62x62 maps" if arena else f"{len(pool)} maps"),
                 "envs_per_gpu": E,
                 "agents_per_env": A,
                 "groups": G,
@@ -446,6 +554,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
+                "algorithmic_bytes_per_agent_step": algo_agent,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -31,6 +31,32 @@ def bench_shard(rank: int, envs_per_rank: int, pool_len: int, base_seed: int = 0
     return [(base_seed + g) & 0xFFFFFFFF for g in ids], [g % pool_len for g in ids]
 
 
+def bench_workload(name: str, small: bool = False) -> dict:
+    """The workloads `bench.py --workload` shards over ranks (BASELINE configs[1], [3], [4]); `small` = the same
+    configuration family at a size the CPU oracle steps in seconds (tests/test_dist_cpu.py).  `maps` is None where the
+    caller loads the committed pool of reference-generated arena maps."""
+    from .builder import make_arena, make_combat_stress
+
+    if name in ("arena", "rollout"):
+        return {
+            "name": name, "cfg": make_arena(24), "maps": None, "agents": 24, "envs": 4096, "num_actions": 5,
+            # (rollout: one group -- the policy's kernels serialise on the GPU anyway, and two half-size groups double
+            # the host's launch work per step: 1.03 against 0.67 ms/step)
+            "groups": 4 if name == "arena" else 1,
+            "describe": "arena envs x 24 agents per GPU (BASELINE configs[1])" if name == "arena"
+            else "arena envs x 24 agents per GPU + LSTM policy forward and sampling in bf16 (BASELINE configs[4])",
+        }  # fmt: skip
+    if name == "combat":
+        agents, side = (64, 32) if small else (1024, 256)
+        cfg = make_combat_stress(agents, side)
+        return {
+            "name": name, "cfg": cfg, "maps": [cfg.game.map_builder.build(np.random.default_rng(i)) for i in range(4)],
+            "agents": agents, "envs": 64, "num_actions": 8, "groups": 1,
+            "describe": f"combat-stress envs x {agents} agents on {side}x{side} maps per GPU (BASELINE configs[3])",
+        }  # fmt: skip
+    raise ValueError(f"unknown workload {name!r}: arena, combat or rollout")
+
+
 def all_reduce_summary(summary: np.ndarray, device=None) -> np.ndarray:
     """Sum the per-rank summary vector [episodes, sum(len), sum(reward), game stat sums...] over all ranks."""
     import torch

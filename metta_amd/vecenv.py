@@ -576,7 +576,10 @@ class MettaGridDeviceVecEnv:
             keyed = self.__dict__.get("_keyed_slots")
             if keyed is None:
                 keyed = self._keyed_slots = np.array([bool(nm) and nm[0] != "\x00" for nm in names0])
-            sums_all = (av.astype(np.float64) * at).sum(axis=1) / A  # [n, SA]
+            # (no operators on large temporaries here: numpy's temporary elision walks the call stack the first time
+            # it considers one -- 80-250 ms with torch's libraries loaded, and it would land in some step's send())
+            sums_all = np.multiply(av, at, dtype=np.float64).sum(axis=1)  # [n, SA]
+            sums_all /= A
             any_all = at.any(axis=1) & keyed[None, :]
             tab_any = av[:, :, -n_tab + 1 :: 2].any(axis=(1, 2))
         heart = self.__dict__.get("_heart_slot")

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from metta_amd.dist import shard_range, shard_seeds, summary_to_metrics
@@ -93,17 +94,19 @@ def test_summary_all_reduce_gloo_world2():
     assert "game/tokens_dropped" not in m
 
 
-def _shard_summary(rank, world, E, T):
-    """[envs, env-steps, sum of rewards] of rank's bench shard stepped on the oracle with per-global-id actions."""
-    from metta_amd.builder import make_arena
+def _shard_summary(rank, world, E, T, workload="arena"):
+    """[envs, env-steps, sum of rewards] of rank's bench shard stepped on the oracle with per-global-id actions: the
+    configuration, pool and action range `bench.py --workload <workload>` uses (`bench_workload`; combat at a size the
+    oracle steps in seconds, the rollout workload shards exactly like arena)."""
     from metta_amd.compile import compile_game
-    from metta_amd.dist import bench_shard
+    from metta_amd.dist import bench_shard, bench_workload
     from oracle.mg_oracle import make_oracle_env
     from tests.helpers import load_map_pool
 
-    pool = load_map_pool()
-    comp = compile_game(make_arena(24), init_obs_passes=2)
-    acts = np.random.default_rng(5).integers(0, 5, size=(T, 4 * E, 24)).astype(np.int32)  # indexed by GLOBAL env id
+    wl = bench_workload(workload, small=True)
+    pool = wl["maps"] or load_map_pool()
+    comp = compile_game(wl["cfg"], init_obs_passes=2)
+    acts = np.random.default_rng(5).integers(0, wl["num_actions"], size=(T, 4 * E, wl["agents"])).astype(np.int32)  # by GLOBAL env id
     seeds, maps = bench_shard(rank, E * (1 if world > 1 else 2), len(pool))
     out = np.zeros(3)
     for e, (s, m) in enumerate(zip(seeds, maps)):
@@ -117,7 +120,7 @@ def _shard_summary(rank, world, E, T):
     return out
 
 
-def _shard_worker(rank, world, port, q):
+def _shard_worker(rank, world, port, q, workload="arena"):
     import torch.distributed as dist
 
     from metta_amd.dist import all_reduce_summary
@@ -125,25 +128,27 @@ def _shard_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = all_reduce_summary(_shard_summary(rank, world, 3, 40))
+    out = all_reduce_summary(_shard_summary(rank, world, 3, 40, workload))
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, out.tolist()))
 
 
-def test_two_ranks_of_E_envs_reduce_to_one_handle_of_2E_envs_gloo():
+@pytest.mark.parametrize("workload", ["arena", "combat", "rollout"])
+def test_two_ranks_of_E_envs_reduce_to_one_handle_of_2E_envs_gloo(workload):
     """World 2 over gloo: each rank steps its bench shard on the oracle, the summary all-reduce equals the summary of
-    one process holding all 2E environments (no data-path collective)."""
+    one process holding all 2E environments (no data-path collective) -- for every workload `bench.py`
+    shards (configs[1], [3], [4])."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, workload)) for r in range(2)]
     [p.start() for p in ps]
     res = dict(q.get(timeout=180) for _ in range(2))
     [p.join(timeout=60) for p in ps]
-    one = _shard_summary(0, 1, 3, 40)
+    one = _shard_summary(0, 1, 3, 40, workload)
     assert res[0] == res[1] and res[0][:2] == [6.0, 240.0] == one[:2].tolist()
     assert abs(res[0][2] - one[2]) < 1e-9  # f64 sum of f32 rewards, associated per rank
 
