@@ -36,7 +36,14 @@
 // and a third time (k_fused_nomod_o7.hip) for 7 instead of 8 waves per SIMD: 72 registers, no vector spills, 14
 // workgroups per CU -- the better build whenever the launch is not exactly one round of 16 workgroups per CU (small
 // groups stepped on several streams, or more environments than one round holds).
-#if defined(MG_NO_MODIFIERS) && defined(MG_FUSED_W1)
+#if defined(MG_NO_MODIFIERS) && defined(MG_FUSED_W18)
+#define mg_step_fused_kernel mg_step_fused_nomod_w18_kernel
+#define mg_launch_fused mg_launch_fused_nomod_w18
+#define mg_fused_lds_bytes mg_fused_lds_bytes_nomod_w18
+#define mg_raise_lds_cap_fused mg_raise_lds_cap_fused_nomod_w18
+#define MG_FUSED_OCC 8
+#define MG_FUSED_THREADS 64
+#elif defined(MG_NO_MODIFIERS) && defined(MG_FUSED_W1)
 // (k_fused_nomod_w1.hip: ONE wave per environment, for environments of a few agents -- navigation has 4 -- where a
 // second wave only repeats the scalar work and idles through the single-wave phases)
 #define mg_step_fused_kernel mg_step_fused_nomod_w1_kernel

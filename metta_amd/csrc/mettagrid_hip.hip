@@ -166,6 +166,7 @@ struct mg_handle {
   std::vector<void*> map_allocs;
   size_t lds_bytes = 0, lds_act = 0, lds_obs = 0, lds_uses = 0, lds_fused = 0, lds_fused_w1 = 0;
   bool fused_w1 = false;  // the one-wave-per-environment build of the fused kernel (few agents, no modifiers)
+  bool fused_w18 = false; // ... its 8-waves-per-SIMD build (32 workgroups per CU)
   FusedLds fl2, fl1;      // LDS layouts of the two-wave builds / the one-wave build (handed over in the kernel arguments)
   bool dc_lds = false;
   bool fused = false;              // fast configs: the whole step in one launch (k_fused.hip)
@@ -681,6 +682,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
         HIPCHK(mg_raise_lds_cap_fused_nomod_o7((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_o6((int)LDS_MAX));
         HIPCHK(mg_raise_lds_cap_fused_nomod_w1((int)LDS_MAX));
+        HIPCHK(mg_raise_lds_cap_fused_nomod_w18((int)LDS_MAX));
         // A few agents per environment (navigation: 4): one wave does the whole step; a second one would repeat the
         // scalar work and wait through the action and use phases.  MG_FUSED_W1=0/1 overrides.
         h->lds_fused_w1 = mg_fused_lds_bytes_nomod_w1(k, h->fused_dcl);
@@ -691,7 +693,31 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
           if (b2 != h->lds_fused || b1 != h->lds_fused_w1) return fail("mg_set_maps: fused LDS layouts disagree (internal)");
         }
         h->fused_w1 = h->no_modifiers && c.A <= 8 && h->lds_fused_w1 <= LDS_MAX;
-        if (const char* w1 = getenv("MG_FUSED_W1")) h->fused_w1 = h->no_modifiers && w1[0] == '1' && h->lds_fused_w1 <= LDS_MAX;
+        h->fused_w18 = false;
+        {
+          // One launch steps all E environments.  When they do not fit one round of resident workgroups, the ones left
+          // over start as the first finish and run through a CU that empties around them: 4096 arena environments on
+          // 256 CUs take 0.060 ms where 3584 (one round of 14 per CU) take 0.046.  A build that holds them all at once
+          // wins then, although it is the slower one at every other count (arena as ONE wave per environment, 16 per
+          // CU by LDS: 0.056 ms; navigation at 8 waves per SIMD, 32 per CU: 0.029 against 0.033 ms for 8192).
+          hipDeviceProp_t prop;
+          HIPCHK(hipGetDeviceProperties(&prop, h->device));
+          const long cus = prop.multiProcessorCount, lds_cu = 160 * 1024;
+          auto round = [&](size_t lds, int waves_per_wg, int occ) {
+            return cus * std::min<long>(4 * occ / waves_per_wg, lds ? (long)(lds_cu / lds) : 64);
+          };
+          if (h->no_modifiers && h->lds_fused_w1 <= LDS_MAX) {
+            if (c.A > 8) {
+              if (h->E > round(h->lds_fused, 2, 7) && h->E <= round(h->lds_fused_w1, 1, 7)) h->fused_w1 = true;
+            } else if (h->E > round(h->lds_fused_w1, 1, 7) && h->E <= round(h->lds_fused_w1, 1, 8)) {
+              h->fused_w18 = true;
+            }
+          }
+        }
+        if (const char* w1 = getenv("MG_FUSED_W1")) {  // 0 / 1 / 8: two waves, one wave, one wave at 8 waves per SIMD
+          h->fused_w1 = h->no_modifiers && (w1[0] == '1' || w1[0] == '8') && h->lds_fused_w1 <= LDS_MAX;
+          h->fused_w18 = h->fused_w1 && w1[0] == '8';
+        }
         // The builds with the larger register budget (7 waves per SIMD, 72 registers, 92 scalar registers; 6 waves with
         // limit modifiers) are the default.  The 8-wave builds (64 registers and, on this hardware, 76 scalar ones) spill
         // in every phase: they won in round 2 for exactly one round of 16 workgroups per CU, and lose everywhere since the
@@ -1151,7 +1177,7 @@ static int mg_task_stream(mg_handle* h, const int32_t* cfg_blob, size_t cfg_word
   if (mg_has_modifiers(v)) {
     h->slot_has_modifiers = true;
     h->no_modifiers = false;
-    h->fused_w1 = false;  // (the one-wave build exists without modifiers only)
+    h->fused_w1 = h->fused_w18 = false;  // (the one-wave builds exist without modifiers only)
   }
   return 0;
 }
@@ -1363,7 +1389,8 @@ static int mg_step_impl(mg_handle* h, const int32_t* actions, void* stream, bool
     if (h->fused) {
       if (obs_only) (void)hipEventRecord(h->ev[2 * slot], s);
       kg.fl = (h->no_modifiers && h->fused_w1) ? h->fl1 : h->fl2;
-      if (h->no_modifiers && h->fused_w1) mg_launch_fused_nomod_w1(kg, n, h->lds_fused_w1, h->fused_dcl, st);
+      if (h->no_modifiers && h->fused_w1 && h->fused_w18) mg_launch_fused_nomod_w18(kg, n, h->lds_fused_w1, h->fused_dcl, st);
+      else if (h->no_modifiers && h->fused_w1) mg_launch_fused_nomod_w1(kg, n, h->lds_fused_w1, h->fused_dcl, st);
       else if (h->no_modifiers && h->fused_o7) mg_launch_fused_nomod_o7(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->no_modifiers) mg_launch_fused_nomod(kg, n, h->lds_fused, h->fused_dcl, st);
       else if (h->fused_o7) mg_launch_fused_o6(kg, n, h->lds_fused, h->fused_dcl, st);
@@ -1531,7 +1558,7 @@ int mg_debug_inject_error(mg_handle* h, int env, uint32_t bits) {
 const char* mg_step_path(mg_handle* h) {
   if (!h || !h->maps_set) return "";
   if (h->fused)
-    return h->no_modifiers ? (h->fused_w1 ? "mg_step_fused_nomod_w1_kernel" : h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel")
+    return h->no_modifiers ? (h->fused_w1 ? (h->fused_w18 ? "mg_step_fused_nomod_w18_kernel" : "mg_step_fused_nomod_w1_kernel") : h->fused_o7 ? "mg_step_fused_nomod_o7_kernel" : "mg_step_fused_nomod_kernel")
                            : (h->fused_o7 ? "mg_step_fused_o6_kernel" : "mg_step_fused_kernel");
   if (h->k.fast) return "mg_act_fast_kernel + mg_uses_kernel + mg_obs_kernel";
   return "mg_act_kernel + mg_obs_kernel";

@@ -1402,6 +1402,8 @@ hipError_t mg_raise_lds_cap_fused_nomod_o7(int cap);
 void mg_launch_fused_nomod_w1(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_nomod_w1.hip
 size_t mg_fused_lds_bytes_nomod_w1(const KArgs& k, bool dcl);
 hipError_t mg_raise_lds_cap_fused_nomod_w1(int cap);
+void mg_launch_fused_nomod_w18(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_nomod_w18.hip
+hipError_t mg_raise_lds_cap_fused_nomod_w18(int cap);
 void mg_launch_fused_o6(const KArgs& k, unsigned n, size_t lds, bool dcl, hipStream_t st);  // k_fused_o6.hip
 hipError_t mg_raise_lds_cap_fused_o6(int cap);
 // the cap on dynamic LDS is a per-function setting shared by every handle of the process

@@ -66,9 +66,9 @@ def _compare_state(b, oras, t):
 @pytest.mark.parametrize(
     "path_env",
     [{}, {"MG_DIAG": "8"}, {"MG_FORCE_GENERAL": "1"}, {"MG_FUSED_O7": "0"}, {"MG_FUSED_O7": "0", "MG_DIAG": "8"}, {"MG_NO_FUSED": "1"},
-     {"MG_FUSED_W1": "1"}, {"MG_FUSED_W1": "1", "MG_DIAG": "8"}],
+     {"MG_FUSED_W1": "1"}, {"MG_FUSED_W1": "1", "MG_DIAG": "8"}, {"MG_FUSED_W1": "8"}],
     ids=["fast", "fast-serial-redraw", "general", "fused-8-waves-build", "fused-8-waves-build-serial-redraw", "three-launch",
-         "fused-one-wave-build", "fused-one-wave-build-serial-redraw"],
+         "fused-one-wave-build", "fused-one-wave-build-serial-redraw", "fused-one-wave-8-waves-build"],
 )
 def test_arena_vs_oracle(path_env, monkeypatch):
     """The same comparison through each act-kernel path: the wave-parallel fast kernel (+ the assembler-use
@@ -382,11 +382,16 @@ def test_auto_reset_matches_puffer_semantics():
     b.close()
 
 
-def test_mixed_map_sizes_vs_oracle():
+@pytest.mark.parametrize("path_env", [{}, {"MG_FUSED_W1": "8"}, {"MG_FUSED_W1": "0"}], ids=["one-wave", "one-wave-8-waves-build", "two-waves"])
+def test_mixed_map_sizes_vs_oracle(path_env, monkeypatch):
     """BASELINE config 3 (navigation suite): one pool holding maps of different sizes.  Bounds, the compass token
-    (towards the centre of the map being played) and auto-reset across sizes against one oracle per (env, map)."""
+    (towards the centre of the map being played) and auto-reset across sizes against one oracle per (env, map) --
+    through every build of the fused kernel a navigation handle can land on (the library picks by environment count)."""
     from metta_amd.mapgen import RandomMapBuilder
     from oracle.mg_oracle import make_oracle_env
+
+    for k, v in path_env.items():
+        monkeypatch.setenv(k, v)
 
     cfg = make_navigation(4)
     cfg.game.global_obs.compass = True
@@ -403,6 +408,8 @@ def test_mixed_map_sizes_vs_oracle():
     cur_map = [e % len(maps) for e in range(E)]
     b = _batch(cfg, maps, E, seeds, list(cur_map))
     b.set_auto_reset(True, 1)
+    want = {"": "mg_step_fused_nomod_w1_kernel", "8": "mg_step_fused_nomod_w18_kernel", "0": "mg_step_fused_nomod_o7_kernel"}
+    assert b.step_path() == want[path_env.get("MG_FUSED_W1", "")], b.step_path()
     assert b.env_map_dims(3) == (44, 72) and b.env_map_dims(2) == (9, 9)
     comp = compile_game(cfg, init_obs_passes=2)
     oras = [make_oracle_env(comp, comp.encode_map(maps[m]), s) for s, m in zip(seeds, cur_map)]
@@ -512,6 +519,10 @@ def test_full_size_properties():
     map_ids = [e % P for e in range(E)]
     b1 = _batch(cfg, maps, E, seeds, map_ids)
     b2 = _batch(cfg, maps, E, seeds, map_ids)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        # more environments than one round of the two-wave build holds (14 per CU), at most one round of the one-wave
+        # build (16 per CU by LDS): the library steps them all at once with the latter
+        assert b1.step_path() == "mg_step_fused_nomod_w1_kernel", b1.step_path()
     g = torch.Generator(device="cpu").manual_seed(0)
     K = 64
     base_actions = torch.randint(0, 5, (K, 512, A), generator=g, dtype=torch.int32)

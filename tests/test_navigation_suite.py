@@ -73,6 +73,8 @@ def test_navigation_suite_8192_envs():
     b.reset(seeds=seeds, map_ids=[e % P for e in range(E)])
     b.set_auto_reset(False)
     assert "fused" in b.step_path()
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert b.step_path() == "mg_step_fused_nomod_w18_kernel"  # 8192 > one round of 28 per CU, = one round of 32
     Tmax = int(ms.max())
     acts = np.zeros((Tmax, P, A), np.int32)
     for k, ent in enumerate(meta["entries"]):
