@@ -147,6 +147,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
     for (int i = tid; i < (a.dc_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.dc)[i];  // padded to x4
   DEnv env = a.env[e];
   const int A = a.A;
+  MG_STAMP(7);
 
   const bool do_reset = a.auto_reset && env.done;  // block-uniform
   if (do_reset) mg_restart_env(a, e, env, tid, nt);
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   for (int i = tid; i < mg_act_claims(A); i += nt) x.claim[i] = 0u;
   if (tid < 16) l.flags[tid] = 0;
   __syncthreads();
+  MG_STAMP(8);
   mg_overlay_agents(a, l, tid, nt);
   mg_stage_rng(a, l, e, env.mt_idx, tid, nt);
   env.step += 1;
@@ -189,23 +191,73 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   mg_make_ctx(a, l, cx, e, (int)env.map_id, env.step);
   cx.gset64 = l.gset64;
   __syncthreads();
+  MG_STAMP(9);
 
   // ---- std::shuffle(iota(A), rng) (stl_algo.h:3726-3792) ---------------------------------------
   const int even = (A & 1) == 0 ? 1 : 0;
   const int D = A <= 1 ? 0 : even + (A - (even ? 2 : 1)) / 2;  // draws: U(2) first when A is even, then pairs
   {
+    // One draw per swap step, each from the RNG output at its own index -- unless an earlier draw was rejected (Lemire,
+    // uniform_int_dist.h:258-269) and took a second output: every later draw then reads one output further on.  At 1024
+    // agents 4 % of the environment-steps hold a rejection, so nearly every launch of 256 environments had a few
+    // workgroups on the serial redraw below while the others waited.  Instead: draw, count the rejections before each
+    // step (block scan), draw again where that count changed; settled after (rejections + 1) passes.  A draw rejected
+    // twice in a row, a window that ends, or more steps than threads fall back to the serial form.
     bool reject = false;
-    for (int t = tid; t < D; t += nt) {
-      uint32_t range = 2, s1 = 0;
-      if (!(even && t == 0)) {
-        const uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (t - even));
-        range = (i + 1) * (i + 2);
-        s1 = i + 2;
+    int n_rej = 0;
+    if (D <= nt && !(a.diag & 8)) {
+      int shift = 0;
+      for (int it = 0;; it++) {
+        bool rej = false, hard = false;
+        if (tid < D) {
+          const int t = tid;
+          uint32_t range = 2, s1 = 0;
+          if (!(even && t == 0)) {
+            const uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (t - even));
+            range = (i + 1) * (i + 2);
+            s1 = i + 2;
+          }
+          const uint32_t thr = (0u - range) % range;
+          const int k = t + shift;
+          unsigned long long product = 0;
+          if (k + 1 >= a.NWIN) {
+            hard = true;
+          } else {
+            product = (unsigned long long)l.win[k] * range;
+            if ((uint32_t)product < range && (uint32_t)product < thr) {
+              rej = true;
+              product = (unsigned long long)l.win[k + 1] * range;
+              if ((uint32_t)product < range && (uint32_t)product < thr) hard = true;
+            }
+          }
+          const uint32_t val = (uint32_t)(product >> 32);
+          x.swaps[t] = s1 ? ((val / s1) | ((val % s1) << 16)) : val;
+        }
+        int total = 0;
+        const int before = mg_block_scan_flag(rej, x.wsum, tid, nt, &total);
+        const int state = hard ? 2 : ((tid < D && before != shift) ? 1 : 0);
+        shift = before;
+        n_rej = total;
+        const int any = __syncthreads_or(state);  // bit 0: someone draws again; bit 1: the serial form
+        if ((any & 2) || (any && it >= 8)) {
+          reject = true;
+          break;
+        }
+        if (!any) break;
       }
-      const unsigned long long product = (unsigned long long)(t < a.NWIN ? l.win[t] : 0u) * range;
-      const uint32_t low = (uint32_t)product, val = (uint32_t)(product >> 32);
-      if (low < range && low < (0u - range) % range) reject = true;  // Lemire rejection: the serial form redraws
-      x.swaps[t] = s1 ? ((val / s1) | ((val % s1) << 16)) : val;
+    } else {
+      for (int t = tid; t < D; t += nt) {
+        uint32_t range = 2, s1 = 0;
+        if (!(even && t == 0)) {
+          const uint32_t i = (uint32_t)((even ? 2 : 1) + 2 * (t - even));
+          range = (i + 1) * (i + 2);
+          s1 = i + 2;
+        }
+        const unsigned long long product = (unsigned long long)(t < a.NWIN ? l.win[t] : 0u) * range;
+        const uint32_t low = (uint32_t)product, val = (uint32_t)(product >> 32);
+        if (low < range && low < (0u - range) % range) reject = true;  // Lemire rejection: the serial form redraws
+        x.swaps[t] = s1 ? ((val / s1) | ((val % s1) << 16)) : val;
+      }
     }
     const int any_reject = __syncthreads_or((reject || (a.diag & 8)) ? 1 : 0);
     if (any_reject) {
@@ -217,6 +269,56 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
       }
       __syncthreads();
       for (int p = tid; p < A; p += nt) x.rank[l.order[p]] = (uint16_t)p;
+    } else if (A >= 128 && (mg_act_claims(A) * 2) / A >= 2) {
+      // The element that ends at position p is p walked back through all D swap steps -- D/2 dependent steps per
+      // agent, A^2/4 in total: 38 % of this kernel at 1024 agents.  In blocks instead: B threads each run S = D/B
+      // steps of the forward shuffle on an iota array of their own (M_b = what block b alone does to the positions),
+      // then every agent walks back through the B arrays: p -> M_{B-1}[p] -> ... -> M_0[.].  The arrays borrow the
+      // claim table (unused until the action rounds, cleared again below).
+      uint16_t* M = (uint16_t*)x.claim;
+      int B = (mg_act_claims(A) * 2) / A;  // u16 entries the table holds / A
+      if (B > 32) B = 32;
+      if (B > (nt >> 6)) B = nt >> 6;  // one block per wave: the serial parts run side by side on different SIMDs
+      const int S = (D + B - 1) / B;
+      for (int b = 0; b < B; b++)
+        for (int i = tid; i < A; i += nt) M[b * A + i] = (uint16_t)i;
+      __syncthreads();
+      if ((tid & 63) == 0 && (tid >> 6) < B) {
+        const int b = tid >> 6;
+        uint16_t* m = M + b * A;
+        const int t1 = (b + 1) * S < D ? (b + 1) * S : D;
+        for (int t = b * S; t < t1; t++) {
+          const uint32_t sw = x.swaps[t];
+          if (even && t == 0) {
+            const int j = (int)sw;  // swap(v[1], v[j])
+            const uint16_t u = m[1], w = m[j];
+            m[1] = w;
+            m[j] = u;
+          } else {
+            const int i = (even ? 2 : 1) + 2 * (t - even), pa = (int)(sw & 0xFFFF), pb = (int)(sw >> 16);
+            uint16_t u = m[i], w = m[pa];  // swap(v[i], v[pa]) ...
+            m[i] = w;
+            m[pa] = u;
+            u = m[i + 1];  // ... then swap(v[i+1], v[pb])
+            w = m[pb];
+            m[i + 1] = w;
+            m[pb] = u;
+          }
+        }
+      }
+      __syncthreads();
+      for (int p = tid; p < A; p += nt) {
+        int q = p;
+        for (int b = B - 1; b >= 0; b--) q = M[b * A + q];
+        l.order[p] = (uint16_t)q;
+        x.rank[q] = (uint16_t)p;
+      }
+      if (tid == 0) {
+        l.flags[0] = D + n_rej;
+        l.flags[1] = 0;
+      }
+      __syncthreads();
+      for (int i = tid; i < (B * A + 1) / 2; i += nt) x.claim[i] = 0u;
     } else {
       // the element that ends at position p: walk p back through the swaps (the array starts as iota)
       for (int p = tid; p < A; p += nt) {
@@ -236,12 +338,13 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
         x.rank[q] = (uint16_t)p;
       }
       if (tid == 0) {
-        l.flags[0] = D;
+        l.flags[0] = D + n_rej;
         l.flags[1] = 0;
       }
     }
   }
   __syncthreads();
+  MG_STAMP(10);
 
   // ---- the action loop, in parallel rounds (mettagrid_c.cpp:599-622) ---------------------------------------------------
   const int n_actions = dc[DC_N_ACTIONS], oa = dc[DC_OFF_ACTIONS];
@@ -304,8 +407,12 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
         x.pendf[ai] = 0;
       }
     }
-    if (__syncthreads_or(still) == 0) break;
+    if (__syncthreads_or(still) == 0) {
+      if (a.dbg && tid == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 14] = round;
+      break;
+    }
   }
+  MG_STAMP(11);
   my_overflow |= cx.overflow;
   my_asm_dirty |= cx.asm_dirty;
 
@@ -353,6 +460,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   if (my_overflow) atomicOr(&l.flags[1], 8);
   if (my_asm_dirty) atomicOr(&l.flags[2], 1);
   __syncthreads();
+  MG_STAMP(12);
 
   for (int i = tid; i < A; i += nt) a.exec[(size_t)e * A + i] = l.exec[i];
   mg_flush_stats(a, l, cx, e, tid, nt);
@@ -384,6 +492,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
       if (env.error) atomicOr(&a.status[0], env.error);
     }
   }
+  MG_STAMP(13);
 }
 
 // ---- one kernel instantiation per translation unit (k_act_dcl.hip / k_act_nodcl.hip / k_act_big.hip define

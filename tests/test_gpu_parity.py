@@ -466,6 +466,43 @@ def test_combat_stress_vs_oracle(agents, size, envs, steps):
     b.close()
 
 
+def test_shuffle_rejections_are_redrawn_in_parallel():
+    """std::shuffle draws with Lemire's rejection (uniform_int_dist.h:258-269): a rejected draw takes another RNG output
+    and every later draw moves one output on.  With 1024 agents about 4 % of the environment-steps hold one; the general
+    action kernel settles them with a block scan (k_act_body.h) instead of sending the workgroup through the serial
+    shuffle.  Here: 8 environments x 16 steps must contain rejections (seen as steps that consume more than A/2 outputs
+    -- the shuffle is this configuration's only consumer), and every step equals the oracle."""
+    from oracle.mg_oracle import make_oracle_env  # noqa: F401
+
+    agents, envs, steps = 1024, 8, 16
+    cfg = make_combat_stress(agents, 256)
+    maps = [cfg.game.map_builder.build(np.random.default_rng(70))]
+    seeds = [4000 + e for e in range(envs)]
+    b = _batch(cfg, maps, envs, seeds, [0] * envs)
+    comp, oras = _oracles(cfg, maps, seeds, [0] * envs)
+    nA = len(comp.action_names)
+    rs = np.random.RandomState(5)
+    D = agents // 2
+    idx = b.env_table()[:, 1].astype(np.int64)
+    extra = 0
+    for t in range(1, steps + 1):
+        acts = np.where(rs.rand(envs, agents) < 0.7, rs.randint(1, 5, size=(envs, agents)), rs.randint(0, nA, size=(envs, agents)))
+        acts = acts.astype(np.int32)
+        for e in range(envs):
+            oras[e].step(acts[e])
+        b.step(acts.reshape(-1))
+        _compare_step(b, oras, t, agents)
+        now = b.env_table()[:, 1].astype(np.int64)
+        used = (now - idx) % 624
+        idx = now
+        assert (used >= D).all() and (used <= D + 3).all(), used
+        extra += int((used - D).sum())
+    assert extra >= 2, "no rejected draw in this run: choose other seeds"
+    _compare_state(b, oras, steps)
+    b.check_errors()
+    b.close()
+
+
 def test_vs_reference_core():
     """HIP against the reference's own compiled C++ core (oracle/_ref), when it travelled with the tree."""
     from oracle.ref_bridge import RefEnv, have_reference
