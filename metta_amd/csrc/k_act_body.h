@@ -158,7 +158,10 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
     a.dc = l.dc;
   }
   const int* dc = a.dc;
-  mg_load_grid(a, l, (int)env.map_id, tid, nt);
+  // BIG: the environment's grid in HBM is carried from step to step (moves and swaps update it in place); only a new
+  // episode copies its map and overlays the agents
+  const bool grid_kept = BIG && a.grid_valid && a.grid_valid[e] && !do_reset;  // block-uniform
+  if (!grid_kept) mg_load_grid(a, l, (int)env.map_id, tid, nt);
   if (!BIG) {
     const uint4* src = (const uint4*)(a.agents + (size_t)e * A);
     uint4* dst = (uint4*)l.ag;
@@ -184,7 +187,8 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   if (tid < 16) l.flags[tid] = 0;
   __syncthreads();
   MG_STAMP(8);
-  mg_overlay_agents(a, l, tid, nt);
+  if (!grid_kept) mg_overlay_agents(a, l, tid, nt);
+  if (BIG && a.grid_valid && tid == 0) a.grid_valid[e] = 1;
   mg_stage_rng(a, l, e, env.mt_idx, tid, nt);
   env.step += 1;
   Ctx cx;

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
       for (int i = tid; i < (a.dc_obs_words >> 2); i += nt) ((uint4*)l.dc)[i] = ((const uint4*)a.gdc)[i];
     a.dc = l.dc;
   }
-  mg_load_grid(a, l, (int)env.map_id, tid, nt);
+  const bool grid_kept = BIG && a.grid_valid && a.grid_valid[e];  // (the action kernel left the grid as it is now)
+  if (!grid_kept) mg_load_grid(a, l, (int)env.map_id, tid, nt);
   {
     if (!BIG) {
       const uint4* src = (const uint4*)(a.agents + (size_t)e * a.A);
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
   }
   __syncthreads();
   MG_STAMP(1);
-  mg_overlay_agents(a, l, tid, nt);
+  if (!grid_kept) mg_overlay_agents(a, l, tid, nt);
   __syncthreads();
   MG_STAMP(2);
   if (!(a.diag & 32)) mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);

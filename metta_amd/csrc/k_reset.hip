@@ -80,7 +80,10 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   uint4* d2 = (uint4*)(a.asms + (size_t)e * a.NAmax);
   const uint4* s2 = (const uint4*)l.as;
   for (int i = tid; i < a.NAmax; i += nt) d2[i] = s2[i];
-  if (tid == 0) a.env[e] = env;
+  if (tid == 0) {
+    a.env[e] = env;
+    if (BIG && a.grid_valid) a.grid_valid[e] = 1;
+  }
 }
 
 

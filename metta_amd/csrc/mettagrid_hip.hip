@@ -617,10 +617,13 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   h->lds_bytes = lds;
   h->big = big;
   k.big_grid = nullptr;
+  k.grid_valid = nullptr;
   if (big) {
     uint16_t* bg = nullptr;
     if (dalloc(h, &bg, (size_t)std::max(h->E, num_maps) * HWp, true)) return 1;
     k.big_grid = bg;
+    if (dalloc(h, &k.grid_valid, (size_t)h->E, true)) return 1;  // (zeroed: no grid holds an episode yet)
+    HIPCHK(hipMemset(k.grid_valid, 0, (size_t)h->E));
   }
   const int hw_lds = big ? 0 : HWp, a_rec_obs = big ? 0 : c.A;
   h->dc_lds = !big && k.dc_words <= MG_DC_LDS_MAX_WORDS;
@@ -799,6 +802,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
       uint16_t* tg = nullptr;
       if (dalloc(h, &tg, P * (size_t)HWp, true)) return 1;
       kt.big_grid = tg;
+      kt.grid_valid = nullptr;
     }
     {
       std::vector<int> iota((size_t)P);

@@ -49,6 +49,9 @@ struct KArgs {
   int NCmax, TSC;             // chest slots per map; token-list stride of a chest
   const float* map_objcount;  // [P][n_cells]
   uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
+  uint8_t* grid_valid;        // [E] BIG: big_grid[e] holds the running episode's map with the agents where they stand now
+                              // (the action kernel moves them in place), so a step neither copies the map nor overlays
+                              // the agents again; cleared by whatever replaces the pool, null for template builds
   const int2* map_dims;       // [P] (height, width) of each map; H, W below are the current environment's
   const int* map_max_steps;   // [P] episode length of each map (0 = the configuration's), or null: every map the configuration's
   int max_steps, max_steps_cfg;  // the current environment's / the configuration's max_steps
