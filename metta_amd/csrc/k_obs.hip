@@ -48,6 +48,8 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
     const int4* ai_src = a.map_asm + (size_t)env.map_id * a.NAmax;
     for (int i = tid; i < a.NAmax; i += nt) l.ainfo[i] = ai_src[i];
     if (tid < 3) l.tokacc[tid] = a.gstats[(size_t)e * a.SG + tid];
+    if (BIG)
+      for (int i = tid; i < a.A; i += nt) l.pos[i] = *(const uint32_t*)&l.ag[i];
   }
   __syncthreads();
   MG_STAMP(1);
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
   if (!(a.diag & 32)) mg_build_tokens(a, l, (int)env.map_id, env.step, tid, nt);
   __syncthreads();
   MG_STAMP(3);
-  if (!(a.diag & 16)) mg_encode_all(a, l, e, env.step, l.exec, true, tid, nt);
+  if (!(a.diag & 16)) mg_encode_all<uint16_t, true, false, BIG>(a, l, e, env.step, l.exec, true, tid, nt);
   __syncthreads();
   MG_STAMP(4);
   if (a.diag & 64) return;

@@ -163,6 +163,7 @@ struct Lds {
   uint8_t* ipat;    // fused kernel: [obs_h * obs_w] window cell -> position in the pattern order
   const uint8_t* gmap;  // fused kernel: the byte map of this environment in the HBM pool (static layer)
   int WS;
+  uint32_t* pos;    // observation kernel with the records in HBM (BIG): [A] r | c << 16 of every agent
 };
 
 __host__ __device__ inline size_t mg_align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -278,6 +279,8 @@ __host__ __device__ inline size_t mg_carve_obs(unsigned char* base, Lds* l, int 
   size_t g = take((size_t)HW * 2), ag = take((size_t)(a_rec + (a_rec ? NC : 0)) * sizeof(DAgent)), as = take((size_t)(NA > 0 ? NA : 1) * sizeof(DAsm));
   size_t ex = take((size_t)A * 4), ta = take((size_t)A * 4), tk = take(16), rows = take((size_t)ROWB * nwaves);
   size_t oc = take((size_t)(NOBJ + 1) * 4), hp = take((size_t)HEAP * 2), pt = take((size_t)NP * 4);
+  size_t ps = take(a_rec == 0 ? (size_t)A * 4 : 0);  // (records in HBM: the positions alone are staged)
+  if (FILL) l->pos = a_rec == 0 ? (uint32_t*)(base + ps) : nullptr;
   // the static assembler info is only read while the token lists are built, the row buffers only afterwards
   size_t ai = rows;
   if ((size_t)(NA > 0 ? NA : 1) * 16 > (size_t)ROWB * nwaves) ai = take((size_t)(NA > 0 ? NA : 1) * 16);
@@ -742,7 +745,10 @@ __device__ __forceinline__ int mg_encode_agent(const KArgs& a, const Lds& l, con
 
 // All agents' observations; optionally streamed to HBM.  `exec` holds each agent's executed action (or null = 0).
 // Requires mg_build_tokens + a barrier before.
-template <int NR, bool PAIRS, class CT = uint16_t, bool PAT = true, bool DIRECT = false>
+// PF (records and grid in HBM, BIG): the positions come from LDS (l.pos) and the grid cells of the NEXT group of rows
+// are requested before the current group is encoded, so that their HBM latency runs under the encode instead of in
+// front of it (16 waves of one workgroup per CU have little else to hide it with).
+template <int NR, bool PAIRS, class CT = uint16_t, bool PAT = true, bool DIRECT = false, bool PF = false>
 __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                        bool write_global, int tid, int nt) {
   // (the wave index stays a vector value on purpose: made scalar with readfirstlane, the per-agent address arithmetic
@@ -783,12 +789,42 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   uint32_t roff0 = (uint32_t)(wave * group) * (uint32_t)row_bytes;  // within the env's block of rows (A * T * 3 < 2^32)
   const DAgent* me0 = l.ag + wave * group;
   const uint32_t roff_step = (uint32_t)(nwaves * group) * (uint32_t)row_bytes;
+  uint32_t cvn[group][NR], rcn[group];  // PF: the next group's positions and raw grid cells, in flight
+  auto request = [&](int first) {
+#pragma unroll
+    for (int h = 0; h < group; h++) {
+      const uint32_t p = first + h < a.A ? l.pos[first + h] : 0u;
+      rcn[h] = p;
+      const int ar = (int)(p & 0xFFFF), ac = (int)(p >> 16);
+#pragma unroll
+      for (int q = 0; q < NR; q++) {
+        const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
+        const bool ok = (q * 64 + lane) < ec.P && (unsigned)r < (unsigned)ec.H && (unsigned)c < (unsigned)ec.W;
+        cvn[h][q] = ((const CT*)l.grid)[ok ? __mul24(r, ec.W) + c : 0];
+      }
+    }
+  };
+  if (PF) request(wave * group);
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
   {
     uint32_t meta[group][NR], rc[group];
+    if (PF) {
+#pragma unroll
+      for (int h = 0; h < group; h++) {
+        rc[h] = rcn[h];
+        const int ar = (int)(rc[h] & 0xFFFF), ac = (int)(rc[h] >> 16);
+#pragma unroll
+        for (int q = 0; q < NR; q++) {
+          const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
+          const bool ok = (q * 64 + lane) < ec.P && (unsigned)r < (unsigned)ec.H && (unsigned)c < (unsigned)ec.W;
+          meta[h][q] = l.ocnt[(int)(ok ? cvn[h][q] : 0u) - 1];
+        }
+      }
+      if (a0 + nwaves * group < a.A) request(a0 + nwaves * group);
+    }
 #ifndef MG_ENC_SEQ  // (the lookups of both agents of a pair up front; MG_ENC_SEQ: one agent at a time, fewer live registers)
 #pragma unroll
-    for (int h = 0; h < group; h++) {
+    for (int h = 0; h < group && !PF; h++) {
       if (DIRECT)
         mg_window_lookup_direct<NR>(a, l, ec, me0 + h, dlt, lane, meta[h], rc[h], posj, l.wscr + (size_t)(wave * 2 + h) * l.WS, gm, Wp);
       else
@@ -860,12 +896,12 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
 
 // The headline shape (window of at most 128 cells, rows of 8 mod 16 bytes in pairs: 11 x 11 window, 200 tokens) has
 // a loop of its own, so that the general loop's state stays out of its registers.
-template <class CT = uint16_t, bool PAT = true, bool DIRECT = false>
+template <class CT = uint16_t, bool PAT = true, bool DIRECT = false, bool PF = false>
 __device__ inline void mg_encode_all(const KArgs& a, const Lds& l, int e, uint32_t step, const int* exec,
                                      bool write_global, int tid, int nt) {
   const bool pairs = write_global && (a.A & 1) == 0 && ((a.T * 3) & 15) == 8 && a.ROWB <= 1024;
-  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true, CT, PAT, DIRECT>(a, l, e, step, exec, write_global, tid, nt);
-  else mg_encode_all_t<MG_MAX_ROUNDS, false, CT, PAT, DIRECT>(a, l, e, step, exec, write_global, tid, nt);  // any shape
+  if (pairs && a.dc[DC_PATTERN_N] <= 128) mg_encode_all_t<2, true, CT, PAT, DIRECT, PF>(a, l, e, step, exec, write_global, tid, nt);
+  else mg_encode_all_t<MG_MAX_ROUNDS, false, CT, PAT, DIRECT, PF>(a, l, e, step, exec, write_global, tid, nt);  // any shape
 }
 
 // Sequential f32 accumulation of the tokens_* game stats in agent order (bindings/mettagrid_c.cpp:552-554),
