@@ -31,7 +31,8 @@
 #define MG_ACT_TMP_INTS 128   // 96 + 32 input holders (mg_assembler_use)
 
 struct ActLds {
-  uint32_t* claim;  // [CL] (round << 16) | (0xFFFF - rank) of the best claimant of the cells hashing here
+  uint32_t* claim;  // [CL] (round << 16) | (0xFFFF - rank) of the best claimant of the cell that owns the slot
+  uint32_t* ckey;   // [CL] cell + 1 of the slot's owner (open addressing, linear probing), 0 = free
   int cl_shift;     // 32 - log2(CL)
   uint16_t* rank;   // [A] position of agent i in the shuffled order
   uint8_t* pendf;   // [A] 1 while the agent's action is pending
@@ -64,6 +65,7 @@ __host__ __device__ inline size_t mg_carve_act(unsigned char* base, Lds* l, ActL
   size_t sw = take((size_t)(A / 2 + 2) * 4), ws = take(64 * 4);
   const int CL = mg_act_claims(A);
   size_t cl = take((size_t)CL * 4), tp = take((size_t)MG_ACT_TMP_SLOTS * MG_ACT_TMP_INTS * 4);
+  size_t ck = take((size_t)CL * 4);
   if (FILL) {
     l->dc = (int*)(base + dco);
     l->grid = (uint16_t*)(base + g); l->ag = (DAgent*)(base + ag); l->ch = l->ag + a_rec; l->as = (DAsm*)(base + as);
@@ -73,12 +75,31 @@ __host__ __device__ inline size_t mg_carve_act(unsigned char* base, Lds* l, ActL
     l->gset64 = (unsigned long long*)(base + gs);
     l->gsetv = nullptr; l->gsetm = nullptr; l->tmp = nullptr;
     x->rank = (uint16_t*)(base + rk); x->pendf = base + pf; x->swaps = (uint32_t*)(base + sw); x->wsum = (int*)(base + ws);
-    x->claim = (uint32_t*)(base + cl); x->tmp_pool = (int*)(base + tp);
+    x->claim = (uint32_t*)(base + cl); x->tmp_pool = (int*)(base + tp); x->ckey = (uint32_t*)(base + ck);
     int lg = 0;
     while ((1 << lg) < CL) lg++;
     x->cl_shift = 32 - lg;
   }
   return o;
+}
+
+// The claim slot of a cell.  Slots used to be shared by all cells hashing to them: at 1024 agents a fifth of the claims
+// met a stranger's higher claim, the agent waited a round for nothing, and a step took four or five rounds of three
+// barriers each where the true conflicts need two.  Now a cell owns its slot (the key array; keys stay for the whole
+// step, the round number in the value makes old claims lose).  After MG_CLAIM_PROBES occupied slots the cell shares its
+// home slot with that slot's owner -- every claimant of the cell sees the same occupied slots and lands there too, so
+// real conflicts are never missed, only false ones added.
+#define MG_CLAIM_PROBES 16
+__device__ __forceinline__ uint32_t mg_claim_slot(const ActLds& x, const int cell) {
+  const uint32_t key = (uint32_t)cell + 1u, mask = (1u << (32 - x.cl_shift)) - 1u;
+  const uint32_t home = ((uint32_t)cell * 2654435761u) >> x.cl_shift;
+  uint32_t h = home;
+  for (int i = 0; i < MG_CLAIM_PROBES; i++, h = (h + 1u) & mask) {
+    uint32_t k = x.ckey[h];
+    if (k == 0u) k = atomicCAS(&x.ckey[h], 0u, key);
+    if (k == 0u || k == key) return h;
+  }
+  return home;
 }
 
 // The cells agent `ai`'s action can read or write, as the state stands (every cell is in the map).  Returns whether the
@@ -183,7 +204,10 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
     x.pendf[i] = 1;
   }
   if (tid < MGD_MAX_R) l.gset64[tid] = 0ull;
-  for (int i = tid; i < mg_act_claims(A); i += nt) x.claim[i] = 0u;
+  for (int i = tid; i < mg_act_claims(A); i += nt) {
+    x.claim[i] = 0u;
+    x.ckey[i] = 0u;
+  }
   if (tid < 16) l.flags[tid] = 0;
   __syncthreads();
   MG_STAMP(8);
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
       if (!x.pendf[ai]) continue;
       const uint32_t val = (round << 16) | (0xFFFFu - (uint32_t)x.rank[ai]);
       mg_footprint(cx, ai, acts[ai], n_actions, oa,
-                   [&](int cell) { atomicMax(&x.claim[((uint32_t)cell * 2654435761u) >> x.cl_shift], val); });
+                   [&](int cell) { atomicMax(&x.claim[mg_claim_slot(x, cell)], val); });
     }
     if (tid == 0) l.flags[4] = 0;  // scratch slots handed out this round
     __syncthreads();
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
         const uint32_t val = (round << 16) | (0xFFFFu - (uint32_t)x.rank[ai]);
         bool ok = true;
         const bool nt_ = mg_footprint(cx, ai, acts[ai], n_actions, oa, [&](int cell) {
-          ok = ok && x.claim[((uint32_t)cell * 2654435761u) >> x.cl_shift] == val;
+          ok = ok && x.claim[mg_claim_slot(x, cell)] == val;
         });
         if (ok) ready |= 1u << k;
         if (nt_) needs_tmp |= 1u << k;
@@ -411,6 +435,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
         x.pendf[ai] = 0;
       }
     }
+    if (round == 1) MG_STAMP(15);
     if (__syncthreads_or(still) == 0) {
       if (a.dbg && tid == 0) a.dbg[((size_t)blockIdx.x + a.env_base) * 16 + 14] = round;
       break;

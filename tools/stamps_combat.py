@@ -30,6 +30,7 @@ out = out.astype(np.int64)
 act = out[:, 7:14]
 d = np.diff(act, axis=1)
 print("act kernel phases (stage | overlay+rng | shuffle | action rounds | regen+damage | write-back), medians:", np.median(d, axis=0), "total", np.median(act[:, -1] - act[:, 0]))
+print("first action round:", np.median(out[:, 15] - out[:, 10]), "later rounds together:", np.median(out[:, 11] - out[:, 15]))
 print("action rounds [min, median, max]:", out[:, 14].min(), np.median(out[:, 14]), out[:, 14].max())
 obs = out[:, 0:5]
 d = np.diff(obs, axis=1)
