@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import gzip
 import json
+import logging
 import uuid
 import zlib
 from pathlib import Path
@@ -90,6 +91,7 @@ class EpisodeReplay:
         self.objects: list[dict] = []
         self.total_rewards = np.zeros(batch.num_agents)
         self._index: dict[int, int] = {}
+        self._logged = False  # the first logged step records the static objects too, wherever in the episode it falls
         self._compress, self.content_type = zlib.compress, "application/x-compress"
         h, w = batch.env_map_dims(batch.env_info(self.env)["map_id"])
         self.replay_data = {
@@ -115,7 +117,8 @@ class EpisodeReplay:
     def log_step(self, current_step: int, actions, rewards, action_success) -> None:
         """After step `current_step` of the episode: merge every object's fields into its change lists."""
         self.total_rewards += np.asarray(rewards, dtype=np.float64)
-        objs = self.batch.grid_objects(self.env, ignore_types=() if self.step == 0 else tuple(STATIC_OBJECT_TYPES))
+        objs = self.batch.grid_objects(self.env, ignore_types=() if not self._logged else tuple(STATIC_OBJECT_TYPES))
+        self._logged = True
         for oid, obj in objs.items():
             idx = self._index.get(oid)
             if idx is None:
@@ -151,10 +154,14 @@ def _merge(record: dict, step: int, update: dict) -> None:
 
 
 def _dump(cfg) -> dict:
+    """`sim.config.model_dump(mode="json")` in full, as the reference stores it (replay_log_writer.py:118).  A map builder
+    that does not serialise (a builder object holding arrays, a device pool) is left out with a warning; anything else that
+    fails to serialise is an error, not an empty tree."""
     try:
+        return cfg.model_dump(mode="json")
+    except Exception as ex:
+        logging.getLogger("metta_amd.replay").warning("replay mg_config: game.map_builder left out (%s: %s)", type(ex).__name__, ex)
         return cfg.model_dump(mode="json", exclude={"game": {"map_builder"}})
-    except Exception:
-        return {}
 
 
 class DeviceReplayWriter:

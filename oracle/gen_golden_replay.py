@@ -49,8 +49,34 @@ def main() -> None:
     replay = writer.get_completed_replays()[0].get_replay_data()
     tree = jsonable({k: v for k, v in replay.items() if k != "mg_config"})
     names, codes = encode_names(grid)
+
+    def key_paths(x, prefix=""):  # the shape of the dump: every key path, list positions folded
+        if isinstance(x, dict):
+            out = set()
+            for k, v in x.items():
+                out |= key_paths(v, f"{prefix}/{k}")
+            return out or {prefix}
+        if isinstance(x, list):
+            out = set()
+            for v in x:
+                out |= key_paths(v, prefix + "[]")
+            return out or {prefix}
+        return {prefix}
+
+    mgc = jsonable(replay["mg_config"])
+    game = mgc["game"]
+    actions_cfg = json.loads(json.dumps(game["actions"]))
+    # (the vibe table's display metadata -- symbol, category -- is not part of the fixture: names only)
+    actions_cfg["change_vibe"]["vibes"] = [v["name"] for v in actions_cfg["change_vibe"]["vibes"]]
     out = {"seed": seed, "max_steps": steps, "cell_names": names, "map_shape": list(codes.shape),
-           "map_codes": codes.reshape(-1).tolist(), "actions": actions, "replay": tree}
+           "map_codes": codes.reshape(-1).tolist(), "actions": actions, "replay": tree,
+           # of the embedded `mg_config` (sim.config.model_dump(mode="json"), replay_log_writer.py:118): its key paths
+           # outside the map builder, and the scalar values of a few sections a replay viewer reads
+           "mg_config_key_paths": sorted(p for p in key_paths(mgc) if not p.startswith("/game/map_builder/")),
+           "mg_config_has_map_builder": "map_builder" in game,
+           "mg_config_values": {"label": mgc.get("label"), "num_agents": game["num_agents"], "max_steps": game["max_steps"],
+                                "resource_names": game["resource_names"], "obs": game["obs"],
+                                "actions": actions_cfg}}
     data = zlib.compress(json.dumps(out).encode())
     (GOLD / "replay_arena24.json.z").write_bytes(data)
     print("wrote replay_arena24.json.z", len(data), "bytes;", len(tree["objects"]), "objects,", len(actions), "steps")

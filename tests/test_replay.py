@@ -57,3 +57,65 @@ def test_replay_equals_the_reference_writers(tmp_path):
     disk = json.loads(zlib.decompress(open(path, "rb").read()))
     assert disk["version"] == 3 and len(disk["objects"]) == len(want["objects"]) and "mg_config" in disk
     b.close()
+
+
+def test_mg_config_is_the_full_dump_of_the_reference():
+    """`mg_config` of a replay = `sim.config.model_dump(mode="json")` in full (replay_log_writer.py:118), map builder
+    included.  Against the reference's own dump (fixture: its key paths outside the map builder and the values of the
+    sections a viewer reads): same tree shape, same values; the vibe table's display metadata (symbol, category) is not
+    reproduced by this package -- names and order are."""
+    from metta_amd.builder import make_arena
+    from metta_amd.replay import _dump
+
+    fx = json.loads(zlib.decompress((GOLD / "replay_arena24.json.z").read_bytes()))
+    cfg = make_arena(24)
+    cfg.game.max_steps = fx["max_steps"]
+    d = _dump(cfg)
+
+    def key_paths(x, prefix=""):
+        if isinstance(x, dict):
+            out = set()
+            for k, v in x.items():
+                out |= key_paths(v, f"{prefix}/{k}")
+            return out or {prefix}
+        if isinstance(x, list):
+            out = set()
+            for v in x:
+                out |= key_paths(v, prefix + "[]")
+            return out or {prefix}
+        return {prefix}
+
+    assert ("map_builder" in d["game"]) == fx["mg_config_has_map_builder"]
+    assert sorted(p for p in key_paths(d) if not p.startswith("/game/map_builder/")) == fx["mg_config_key_paths"]
+    want = fx["mg_config_values"]
+    assert d["label"] == want["label"]
+    for k in ("num_agents", "max_steps", "resource_names", "obs"):
+        assert d["game"][k] == want[k], k
+    acts = json.loads(json.dumps(d["game"]["actions"]))
+    acts["change_vibe"]["vibes"] = [v["name"] for v in acts["change_vibe"]["vibes"]]
+    assert acts == want["actions"]
+
+
+@pytest.mark.gpu
+def test_recording_that_begins_mid_episode_still_holds_the_walls():
+    """the static objects are logged with the first step a replay SEES, not only with step 0 of the episode."""
+    from metta_amd.batch import MettaGridBatch
+    from metta_amd.builder import make_arena
+    from metta_amd.replay import DeviceReplayWriter
+    from tests.helpers import load_map_pool
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 30
+    b = MettaGridBatch(cfg, 1, load_map_pool()[:1], device=0, seeds=[3], map_ids=[0])
+    b.set_auto_reset(False)
+    rs = np.random.RandomState(1)
+    for _ in range(7):
+        b.step(rs.randint(0, 5, 24).astype(np.int32))
+    w = DeviceReplayWriter(b, env=0)
+    for _ in range(23):
+        b.step(rs.randint(0, 5, 24).astype(np.int32))
+        w.on_step()
+    (rep,) = w.get_completed_replays()
+    types = {o["type_name"] if not isinstance(o["type_name"], list) else o["type_name"][-1][1] for o in rep.get_replay_data()["objects"]}
+    assert "wall" in types and "agent" in types
+    b.close()
