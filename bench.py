@@ -523,8 +523,11 @@ def main() -> None:
         if tfile.exists():
             try:
                 tj = json.loads(tfile.read_text())
+                one = tj.get("round3_single_stream_4096_envs_per_launch", {})
                 if arena and tj.get("envs_per_launch", tj.get("envs")) == n:
                     traffic = tj.get("hbm_bytes_per_launch")
+                elif arena and G == 1 and n == 4096 and one.get("kernel", "").split(" ")[0] == step_path:
+                    traffic = one.get("hbm_bytes_per_launch")  # the one-handle form was counted in passes of its own
             except Exception:
                 traffic = None
         out = {
