@@ -521,7 +521,6 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
     w.i(0 if clip is None else 1)
     if clip is not None:
         w.i(clip.length_scale, clip.scaled_cutoff_distance, clip.clip_period, len(clip.unclipping_protocols))
-        shapes = set()
         for pc in clip.unclipping_protocols:
             for v in pc.vibes:
                 if v not in vid:
@@ -539,19 +538,12 @@ def compile_game(cfg: GameConfig | MettaGridConfig, init_obs_passes: int = 2) ->
             for v in vids:
                 key = ((key << 8) | v) & ((1 << 64) - 1)
             w.i(key & 0xFFFFFFFF, (key >> 32) & 0xFFFFFFFF)
-            shapes.add((key, pc.min_agents, sum(v > 0 for _, v in ins), sum(v > 0 for _, v in outs)))
             unclip_protocol_listing.append({"inputs": dict(ins), "outputs": dict(outs), "cooldown": pc.cooldown,
                                             "min_agents": pc.min_agents, "vibes": list(vids)})  # fmt: skip
-        # An assembler that starts clipped draws its unclipping protocol from the environment's seed when the Clipper is
-        # built (clipper.hpp:107-110,186-193).  The episode-start templates are per map, not per seed: they hold the
-        # `tokens_*` statistics of the initial observations, which count that protocol's input / output tokens.
-        if (len(shapes) > 1 and game.protocol_details_obs
-                and any(o.start_clipped and not o.clip_immune for o in assemblers)):  # fmt: skip
-            raise NotImplementedError(
-                "clipper: assemblers that start clipped, with unclipping protocols that differ in vibes, min_agents or "
-                "the number of non-zero inputs / outputs, and protocol_details_obs: the initial token statistics would "
-                "depend on the seed (per-map episode templates cannot hold them)"
-            )
+        # (An assembler that starts clipped draws its unclipping protocol from the environment's seed when the Clipper
+        # is built, clipper.hpp:107-110,186-193.  When the protocols differ in shape the `tokens_*` statistics of the
+        # initial observations differ per environment: the device recounts them at every restart instead of taking
+        # them from the per-map template, mg_recount_initial_tokens.)
     w.i(len(agent_slot_names[0]) if agent_slot_names else 0, len(game_slot_names))
     w.i(MG_BLOB_MAGIC)
 

@@ -220,6 +220,9 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   cx.gset64 = l.gset64;
   __syncthreads();
   MG_STAMP(9);
+  if (do_reset && a.clip_w && dc[DC_CLIPPER] && dc[DC_PROTO_OBS] && dc[DC_INIT_PASSES] > 1 && mg_act_claims(A) >= 2 * A + 4 &&
+      !(a.diag & 1048576))  // (1048576: the template's figures, to show that the recount is what the test sees)
+    mg_recount_initial_tokens(a, l, e, (int)env.map_id, (int*)x.claim, tid, nt);  // (the claim table is idle until the rounds)
 
   // ---- std::shuffle(iota(A), rng) (stl_algo.h:3726-3792) ---------------------------------------
   const int even = (A & 1) == 0 ? 1 : 0;

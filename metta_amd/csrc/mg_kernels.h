@@ -921,6 +921,68 @@ __device__ inline void mg_token_stats(const KArgs& a, const Lds& l, int passes) 
   l.tokacc[2] = f;
 }
 
+// The tokens_* statistics of the constructor's observation passes (mettagrid_c.cpp:139-154: one pass before the Clipper
+// exists, init_obs_passes - 1 after it) for THIS environment as it stands right after a restart.  The episode-start
+// templates hold them per MAP; with a Clipper whose start-clipped stations draw their unclipping protocol from the
+// environment's seed (clipper.hpp:107-110,186-193) and protocol tokens in the observations, the later passes differ per
+// environment whenever the protocols differ in shape.  Needs the grid with the agents overlaid, the records and the
+// station records staged (`l`), and 2A + 4 zeroed ints of LDS (`scr`, left zero again); all threads of the workgroup.
+template <class CT = uint16_t>
+__device__ inline void mg_recount_initial_tokens(const KArgs& a, const Lds& l, int e, int map_id, int* scr, int tid, int nt) {
+  const int* dc = a.dc;
+  const EncCfg ec = mg_enc_cfg(a);
+  const CellCodec cc{a.NW, a.A, a.NAmax};
+  const int4* asm_info = a.map_asm + (size_t)map_id * a.NAmax;
+  const int4* chest_info = a.map_chest + (size_t)map_id * a.NCmax;
+  const CT* grid = (const CT*)l.grid;
+  int* att1 = scr, *att2 = scr + a.A, *sums = scr + 2 * a.A;  // attempted tokens of the first / the later passes
+  for (int w = tid; w < a.A * ec.P; w += nt) {
+    const int ai = w / ec.P, p = w - ai * ec.P;
+    const uint32_t pk = mg_pattern_entry(a.gdc, p);
+    const int r = (int)l.ag[ai].r + (int)(pk & 0xFF) - 8, c = (int)l.ag[ai].c + (int)((pk >> 8) & 0xFF) - 8;
+    if ((unsigned)r >= (unsigned)ec.H || (unsigned)c >= (unsigned)ec.W) continue;
+    const uint16_t cv = (uint16_t)grid[r * ec.W + c];
+    if (cv == 0) continue;
+    CountOut n2{0};
+    mg_object_tokens(dc, grid, l.ag, l.as, asm_info, cc, ec.H, ec.W, 0u, cv, n2, l.ch, chest_info);
+    int n1 = n2.n;
+    if (cc.kind(cv) == MG_CELL_ASSEMBLER && l.as[cc.asm_idx(cv)].clipped >= 2u) {
+      // before the Clipper was built the station was plainly clipped: the flag, no protocol tokens
+      DAsm before = l.as[cc.asm_idx(cv)];
+      before.clipped = 1u;
+      CountOut c1{0};
+      // (the station list is indexed by the cell's station index: hand over a pointer that puts `before` there)
+      mg_object_tokens(dc, grid, l.ag, &before - cc.asm_idx(cv), asm_info, cc, ec.H, ec.W, 0u, cv, c1, l.ch, chest_info);
+      n1 = c1.n;
+    }
+    atomicAdd(&att1[ai], n1);
+    atomicAdd(&att2[ai], n2.n);
+  }
+  __syncthreads();
+  const GlobalTok gt = mg_global_tok(a, 0u, 0);
+  const int later = dc[DC_INIT_PASSES] - 1;
+  for (int ai = tid; ai < a.A; ai += nt) {
+    int base = gt.n;
+    if (ec.g_goal) base += L_n(dc, group_rec(dc, l.ag[ai].group)[GR_OFF_GOAL]);
+    if (ec.g_compass) {
+      const int dr = ec.H / 2 - (int)l.ag[ai].r, dcc = ec.W / 2 - (int)l.ag[ai].c;
+      const int sr = dr != 0 ? (dr > 0 ? 1 : -1) : 0, sc = dcc != 0 ? (dcc > 0 ? 1 : -1) : 0;
+      const int orr = ec.hr + sr, occ = ec.wr + sc;
+      if ((sr != 0 || sc != 0) && orr >= 0 && orr < ec.oh && occ >= 0 && occ < ec.ow) base++;
+    }
+    const int a1 = att1[ai] + base, a2 = att2[ai] + base;
+    const int w1 = a1 < a.T ? a1 : a.T, w2 = a2 < a.T ? a2 : a.T;
+    atomicAdd(&sums[0], w1 + later * w2);
+    atomicAdd(&sums[1], (a1 - w1) + later * (a2 - w2));
+    atomicAdd(&sums[2], (a.T - w1) + later * (a.T - w2));
+  }
+  __syncthreads();
+  if (tid < 3) a.gstats[(size_t)e * a.SG + tid] = (float)sums[tid];  // (integers below 2^24: exact in f32 in any order)
+  __syncthreads();
+  for (int i = tid; i < 2 * a.A + 4; i += nt) scr[i] = 0;
+  __syncthreads();
+}
+
 // Fresh episode state in LDS + zeroed global stats (MettaGrid ctor: bindings/mettagrid_c.cpp:46-155,159-245).
 __device__ inline void mg_reset_env(const KArgs& a, const Lds& l, Ctx& cx, int e, int map_id, uint32_t seed, int tid,
                                     int nt) {

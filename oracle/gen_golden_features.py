@@ -30,7 +30,7 @@ sys.path.insert(0, str(ROOT))
 from oracle.gen_golden import GOLD, digest, encode_names, install_reference_shims  # noqa: E402
 
 SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
-         119, 127, 130, 133, 141, 143, 145, 146, 155, 164]
+         119, 127, 130, 133, 141, 143, 145, 146, 155, 164, 401, 403, 407]
 # + a Clipper.  The reference picks the next assembler to clip by walking std::set<Assembler*> (clipper.hpp:24-26,
 # 207-229): POINTER order, so two reference instances in one process can disagree (seen here: seed 119 diverges at
 # step 4 between two instances built back to back).  Each of these fixtures is therefore produced by the FIRST
@@ -38,7 +38,10 @@ SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 1
 # creation (row-major) order -- the order oracle/mg_oracle.cpp restates; no second instance runs beside it.
 # (seeds picked for what happens in their 200 steps: 20-60 clip events and as many unclips, stations that start clipped,
 # clip-immune stations, 1-3 unclipping protocols, automatic length scale, clip_period 0 and 1)
-CLIPPER_SEEDS = {119, 127, 130, 133, 141, 143, 145, 146, 155, 164}
+CLIPPER_SEEDS = {119, 127, 130, 133, 141, 143, 145, 146, 155, 164, 401, 403, 407}
+# stations that start clipped under unclipping protocols of DIFFERENT shapes, protocol tokens in the observations: the
+# `tokens_*` statistics of the constructor's passes depend on the environment's seed (which protocol each station drew)
+ANY_SHAPE_SEEDS = {401, 403, 407}
 WIDE_SEEDS = {116: 24, 117: 32}  # resource lists beyond 16: one team starts with every resource (map growth 13 -> 29 -> 59)
 COLLECTIVE_SEEDS = {113, 114, 115}  # + collectives: membership by tag, stat rewards on the collective's statistics
 STEPS = 200
@@ -86,8 +89,11 @@ def main(only: int | None = None) -> None:
             covered["clipper_start_clipped"] = covered.get("clipper_start_clipped", 0) + 1  # (asserted by --only runs below)
             continue
         cfg = rand_cfg(np.random.RandomState(seed), device_safe=True, collectives=seed in COLLECTIVE_SEEDS,
-                       num_resources=WIDE_SEEDS.get(seed, 0), clipper=seed in CLIPPER_SEEDS)
+                       num_resources=WIDE_SEEDS.get(seed, 0), clipper=seed in CLIPPER_SEEDS,
+                       start_clipped_any_shape=seed in ANY_SHAPE_SEEDS)
         game = cfg.game
+        if seed in ANY_SHAPE_SEEDS:
+            game.protocol_details_obs = True
         if seed in WIDE_SEEDS:
             game.agents[0].inventory.initial = {r: int(1 + (i * 7) % 11) for i, r in enumerate(game.resource_names)}
             game.agents[0].inventory.default_limit = 65535

@@ -81,7 +81,7 @@ def add_collectives(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGri
     return cfg
 
 
-def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridConfig:
+def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState, start_clipped_any_shape: bool = False) -> MettaGridConfig:
     """A Clipper (systems/clipper.hpp) over the configuration's assemblers: frequent clip events, a few clip-immune
     and start-clipped stations, unclipping protocols that the agents can sometimes pay (one of them free, so that
     stations do get unclipped and the infection weights go down as well as up)."""
@@ -90,7 +90,9 @@ def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridCon
     game = cfg.game
     R = list(game.resource_names)
     asms = [o for o in game.objects.values() if isinstance(o, AssemblerConfig)]
-    same_shape = bool(rs.randint(3))  # start-clipped stations need unclipping protocols of one shape (compile.py)
+    # (stations start clipped only under protocols of one shape, unless asked otherwise: the fixtures of seeds 119..164
+    # were drawn that way, and the draws below must stay where they are for them)
+    same_shape = bool(rs.randint(3))
     protos = []
     for k in range(int(rs.randint(1, 4))):
         if same_shape:
@@ -108,7 +110,7 @@ def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridCon
         protos = protos[:1]
     for o in asms:
         o.clip_immune = bool(rs.randint(4) == 0)
-        o.start_clipped = bool(same_shape and rs.randint(3) == 0)
+        o.start_clipped = bool((same_shape or start_clipped_any_shape) and rs.randint(3) == 0)
     game.clipper = ClipperConfig(
         unclipping_protocols=protos, length_scale=int(rs.choice([0, 0, 1, 2, 3])),
         scaled_cutoff_distance=int(rs.randint(1, 4)), clip_period=int(rs.choice([1, 2, 3, 5, 0])),
@@ -122,7 +124,7 @@ def add_clipper(cfg: MettaGridConfig, rs: np.random.RandomState) -> MettaGridCon
 
 
 def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: bool = False,
-             num_resources: int = 0, clipper: bool = False) -> MettaGridConfig:  # fmt: skip
+             num_resources: int = 0, clipper: bool = False, start_clipped_any_shape: bool = False) -> MettaGridConfig:  # fmt: skip
     R = RES[: rs.randint(3, len(RES) + 1)]
     if num_resources:  # wide resource lists (17..32: the wide-inventory build of the library)
         R = (RES + [f"res{i}" for i in range(num_resources)])[:num_resources]
@@ -262,7 +264,7 @@ def rand_cfg(rs: np.random.RandomState, device_safe: bool = False, collectives: 
     cfg = MettaGridConfig(game=game)
     if collectives:
         cfg = add_collectives(cfg, rs)
-    return add_clipper(cfg, rs) if clipper else cfg
+    return add_clipper(cfg, rs, start_clipped_any_shape) if clipper else cfg
 
 
 def fuzz_actions(rs: np.random.RandomState, game, n_actions: int, invalid: bool = True) -> np.ndarray:

@@ -203,26 +203,30 @@ def test_fuzz_wide_resource_lists_vs_oracle(seed, num_resources):
     b.close()
 
 
-@pytest.mark.parametrize("seed", list(range(300, 316)))
+@pytest.mark.parametrize("seed", list(range(300, 316)) + list(range(400, 412)))
 def test_fuzz_clipper_vs_oracle(seed):
     """A Clipper (systems/clipper.hpp) on top of the fuzzed configurations: clip events, stations that start clipped,
     unclipping by use, clip-immune stations, clip_period 0, automatic length scale.  Short episodes with auto-reset:
     every restart rebuilds the environment's clipper from its own seed (which unclipping protocol a station that starts
-    clipped offers is drawn there).  Infection weights and the length scale are compared with the oracle's."""
+    clipped offers is drawn there).  Infection weights and the length scale are compared with the oracle's.
+    Seeds from 400: stations start clipped under unclipping protocols of DIFFERENT shapes with protocol tokens in the
+    observations and two constructor passes -- the `tokens_*` statistics of an episode's start then depend on the
+    environment's seed, and a restart recounts them (`mg_recount_initial_tokens`; refused until round 3); the statistics
+    are compared right after every restart."""
     from oracle.mg_oracle import make_oracle_env
 
     rs = np.random.RandomState(seed)
-    cfg = None
-    while cfg is None:
-        cand = rand_cfg(rs, device_safe=True, clipper=True, collectives=bool(seed % 4 == 0))
-        try:
-            compile_game(cand, init_obs_passes=2)
-            cfg = cand
-        except NotImplementedError as ex:  # (start-clipped stations with unclipping protocols of different shapes)
-            assert "start clipped" in str(ex)
+    any_shape = seed >= 400
+    cfg = rand_cfg(rs, device_safe=True, clipper=True, collectives=bool(seed % 4 == 0), start_clipped_any_shape=any_shape)
+    compile_game(cfg, init_obs_passes=2)
     game = cfg.game
     game.max_steps = int(rs.choice([20, 35, 50]))
     passes = int(rs.randint(1, 3))
+    if any_shape:
+        game.protocol_details_obs = True
+        passes = 2
+        if not any(getattr(o, "start_clipped", False) and not getattr(o, "clip_immune", False) for o in game.objects.values()):
+            next(o for o in game.objects.values() if hasattr(o, "start_clipped")).start_clipped = True
     maps = [game.map_builder.build(np.random.default_rng(1000 * seed + i)) for i in range(3)]
     E, A = 4, game.num_agents
     seeds = [seed * 10 + e for e in range(E)]
@@ -244,16 +248,18 @@ def test_fuzz_clipper_vs_oracle(seed):
     _compare_state(b, oras, 0)
     for t in range(1, 141):
         acts = np.stack([fuzz_actions(rs, game, nA) for _ in range(E)])
+        restarted = False
         for e in range(E):
             if oras[e].terminals.all() or oras[e].truncations.all():
                 cur_map[e] = (cur_map[e] + 1) % 3
                 oras[e] = make_oracle_env(comp, comp.encode_map(maps[cur_map[e]]), seeds[e])
+                restarted = True
             oras[e].step(acts[e])
         b.step(acts.reshape(-1))
         _compare_step(b, oras, t, A)
         if t % 10 == 0:
             compare_clipper(t)
-        if t % 35 == 0:
+        if t % 35 == 0 or (any_shape and restarted):
             _compare_state(b, oras, t)
     b.check_errors()
     b.close()
@@ -301,7 +307,7 @@ def test_more_resources_than_the_wide_build_holds_is_an_error():
 
 
 @pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
-                                  119, 127, 130, 133, 141, 143, 145, 146, 155, 164])  # (from 119 on: with a Clipper)
+                                  119, 127, 130, 133, 141, 143, 145, 146, 155, 164, 401, 403, 407])  # (from 119 on: with a Clipper; 40x: start-clipped stations under protocols of different shapes)
 def test_golden_feature_families(seed):
     """tests/golden/feature_<seed>.npz: configurations with attack / armor / loot / freeze, transfer, chests, damage,
     regeneration, partial usage ... converted by the reference's REAL `convert_to_cpp_game_config` and stepped by its

@@ -114,7 +114,7 @@ def test_bridge_matches_reference_python_converter_shapes():
 
 
 FEATURE_SEEDS = [101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117,
-                 119, 127, 130, 133, 141, 143, 145, 146, 155, 164]  # (from 119 on: with a Clipper)
+                 119, 127, 130, 133, 141, 143, 145, 146, 155, 164, 401, 403, 407]  # (from 119 on: with a Clipper; 40x: start-clipped stations under protocols of different shapes)
 
 
 def load_feature_fixture(seed):
