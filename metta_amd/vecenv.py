@@ -82,15 +82,20 @@ class _LazyStats(dict):
     infos should not pay for thirty string-keyed entries of each.  Behaves as the plain dict it becomes."""
 
     __slots__ = ("_pending",)
+    _PLACEHOLDER = "\x00pending"
 
     def __init__(self, fill):
         super().__init__()
         self._pending = fill
+        # C code that asks the table for its size without going through a method (json's encoder returns "{}" for a dict
+        # of size 0 before it ever calls items()) must not mistake an undecoded section for an empty one
+        dict.__setitem__(self, self._PLACEHOLDER, 0)
 
     def _fill(self) -> None:
         f = self._pending
         if f is not None:
             self._pending = None
+            dict.pop(self, self._PLACEHOLDER, None)
             dict.update(self, f())
 
     def __getitem__(self, k):
@@ -143,6 +148,57 @@ class _LazyStats(dict):
     def copy(self):
         self._fill()
         return dict(dict.items(self))
+
+    # (whatever changes or merges the dict sees the decoded entries first: an entry set before the fill must not be
+    # overwritten by it, and C-level copies -- `|`, `dict.copy` -- read the underlying table directly)
+    def __setitem__(self, k, v):
+        self._fill()
+        dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._fill()
+        dict.__delitem__(self, k)
+
+    def update(self, *a, **kw):
+        self._fill()
+        dict.update(self, *a, **kw)
+
+    def setdefault(self, k, default=None):
+        self._fill()
+        return dict.setdefault(self, k, default)
+
+    def pop(self, *a):
+        self._fill()
+        return dict.pop(self, *a)
+
+    def popitem(self):
+        self._fill()
+        return dict.popitem(self)
+
+    def clear(self):
+        self._pending = None
+        dict.clear(self)
+
+    def __sizeof__(self):
+        self._fill()
+        return dict.__sizeof__(self)
+
+    def __or__(self, other):
+        self._fill()
+        return dict.__or__(dict(dict.items(self)), other)
+
+    def __ror__(self, other):
+        self._fill()
+        return dict.__or__(dict(other), dict(dict.items(self)))
+
+    def __ior__(self, other):
+        self._fill()
+        dict.update(self, other)
+        return self
+
+    def __bool__(self):
+        self._fill()
+        return dict.__len__(self) > 0
 
 
 class _Timers:
