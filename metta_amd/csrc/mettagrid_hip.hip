@@ -659,6 +659,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (k.fast && !big && !(nf && nf[0] == '1')) {
       h->cells8 = NOBJ <= 255;  // the kernel reads the static layer from the byte copy of the pool
       h->fused_dcl = k.dc_obs_words <= MG_DC_LDS_MAX_WORDS;
+      if (const char* d = getenv("MG_FUSED_DCL")) h->fused_dcl = h->fused_dcl && d[0] != '0';  // (experiments: no config prefix in LDS)
       h->lds_fused = mg_fused_lds_bytes(k, h->fused_dcl);
       if (h->lds_fused > LDS_MAX / 2 && h->fused_dcl) {  // keep at least two workgroups per CU: drop the config copy first
         h->fused_dcl = false;
