@@ -251,7 +251,8 @@ int mg_finished_rewards(mg_handle* h, int env, float* rewards, uint32_t* steps, 
  * i < to_count - from_count.  The device keeps the last mg_finished_ring_capacity() entries (>= 16 x num_envs, >= 1024;
  * a larger span is an error: read the newest `capacity` entries and count the rest as lost).  Steps still queued while the
  * copy runs append behind `to_count`; they reach the entries being read only after capacity - (to_count - from_count)
- * more episodes.  This replaces a scan over every
+ * more episodes -- and then the call fails instead of returning them: every entry carries its position in the sequence
+ * (12 bits), checked against the range asked for.  This replaces a scan over every
  * environment's episode counter (the reference learns of an episode's end from the step call that ends it,
  * mettagrid_puffer_env.py:158-183; here the host polls).  Entries below a counter value the host has read are complete,
  * so the copy runs on `stream` and waits for nothing else: give it a stream of its own, beside the one the steps are

@@ -573,6 +573,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     while ((1 << k.CB) <= mx) k.CB++;
   }
   if (HEAP > 65535) return fail("mg_set_maps: token lists of one environment exceed 65535 entries");
+  if (num_maps > (1 << 20)) return fail("mg_set_maps: more than 2^20 map slots");
   // LDS plan.  Normal: map tile + records + token lists in LDS.  BIG (the map does not fit): the grid tile of each
   // env lives in HBM, and the observation / reset kernels read the agent records in HBM too.
   const size_t LDS_MAX = 160 * 1024;
@@ -1820,8 +1821,11 @@ int mg_finished_ring(mg_handle* h, uint32_t from_count, uint32_t to_count, int32
   if (first < n) HIPCHK(hipMemcpyAsync(buf.data() + first, h->k.fin_ring, (size_t)(n - first) * sizeof(uint2), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for (uint32_t i = 0; i < n; i++) {
+    if ((buf[i].y >> 20) != ((from_count + i) & 0xFFFu))
+      return fail("mg_finished_ring: entry " + std::to_string(from_count + i) + " was overwritten while the range was read (the device "
+                  "ran more than a ring ahead of the host): read again from a later counter value");
     env_ids[i] = (int32_t)buf[i].x;
-    map_ids[i] = (int32_t)buf[i].y;
+    map_ids[i] = (int32_t)(buf[i].y & 0xFFFFFu);
   }
   return 0;
 }

@@ -1311,7 +1311,9 @@ __device__ inline void mg_snapshot_finished(const KArgs& a, int e, uint32_t step
   if (tid == 0) {
     a.fin_steps[e] = steps;
     const uint32_t idx = atomicAdd(&a.status[1], 1u);
-    if (a.fin_ring) a.fin_ring[idx & a.fin_ring_mask] = make_uint2((uint32_t)e, map_id);
+    // (the upper 12 bits of the second word carry the entry's position in the sequence: a reader that was lapped while
+    // it copied sees the mismatch instead of somebody else's episode; map slots are below 2^20, mg_set_maps checks)
+    if (a.fin_ring) a.fin_ring[idx & a.fin_ring_mask] = make_uint2((uint32_t)e, (map_id & 0xFFFFFu) | (idx << 20));
     atomicAdd(&a.summary[0], 1.0);
     atomicAdd(&a.summary[1], (double)steps);
   }

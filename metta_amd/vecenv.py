@@ -605,7 +605,15 @@ class MettaGridDeviceVecEnv:
             # counted as dropped (an environment among them that finished again later would have been dropped anyway)
             self.episodes_dropped += behind - cap
             self._ring_seen = (upto - cap) & 0xFFFFFFFF
-        envs_all, maps_all = b.finished_ring(self._ring_seen, upto, stream=self._side_stream.cuda_stream)
+        try:
+            envs_all, maps_all = b.finished_ring(self._ring_seen, upto, stream=self._side_stream.cuda_stream)
+        except RuntimeError as ex:
+            if "was overwritten while the range was read" not in str(ex):
+                raise
+            # the steps queued behind this poll finished more than a ring of episodes while it copied: the range is gone
+            self.episodes_dropped += (upto - self._ring_seen) & 0xFFFFFFFF
+            self._ring_seen = upto
+            return
         self._ring_seen = upto
         P, stride = len(b.map_pool), getattr(b, "map_stride", 1)
         last: dict[int, int] = {}

@@ -540,3 +540,30 @@ def test_finished_ring_reports_every_episode_and_counts_overwritten_ones(collect
     assert _json.loads(_json.dumps(one["game"])) == dict(one["game"])  # serialises like the dict it is
     assert one["attributes"]["steps"] <= 6 and one["attributes"]["max_steps"] == 6
     v.close()
+
+
+def test_finished_ring_refuses_a_range_the_device_has_overwritten():
+    """`mg_finished_ring` entries carry their position in the sequence: a range that lies more than a ring behind the
+    counter is refused by size, and a range inside the ring whose entries were overwritten meanwhile (the reader was
+    lapped) is refused by the tags -- never returned as somebody else's episodes."""
+    from metta_amd.batch import MettaGridBatch
+
+    cfg = make_arena(24)
+    cfg.game.max_steps = 2
+    E = 64
+    b = MettaGridBatch(cfg, E, load_map_pool()[:2], device=0, seeds=list(range(E)), map_ids=[e % 2 for e in range(E)])
+    b.set_auto_reset(True, 1)
+    cap = b.finished_ring_capacity()
+    assert cap >= 16 * E and cap >= 1024
+    c0 = int(b.status_tensor()[1].item())
+    acts = np.zeros(E * 24, np.int32)
+    while int(b.status_tensor()[1].item()) - c0 < 2 * cap + 3 * E:
+        b.step(acts)
+    c1 = int(b.status_tensor()[1].item())
+    envs, maps = b.finished_ring(c1 - cap, c1)  # the newest `cap` entries are all there
+    assert len(envs) == cap and set(envs.tolist()) == set(range(E)) and set(maps.tolist()) <= {0, 1}
+    with pytest.raises(RuntimeError, match="the ring holds"):
+        b.finished_ring(c1 - cap - 1, c1)
+    with pytest.raises(RuntimeError, match="was overwritten while the range was read"):
+        b.finished_ring(c1 - cap - 10, c1 - cap + 5)  # inside the size limit, but its first entries are gone
+    b.close()
