@@ -118,7 +118,7 @@ __device__ __forceinline__ bool mg_footprint(const Ctx& cx, const int ai, const 
   const int tr = r + dy, tc = c + dx;
   if (tr < 0 || tc < 0 || tr >= cx.H || tc >= cx.W) return false;
   f(tr * cx.W + tc);
-  const uint16_t target = cx.grid[tr * cx.W + tc];
+  const uint16_t target = cx.grid[tr * cx.GW + tc];
   if (cx.cc.kind(target) != MG_CELL_ASSEMBLER) return false;  // static objects never move: safe to read at any time
   // Assembler::onUse reads and writes the agents on the ring and the chests inside the search square (assembler.hpp:
   // 48-122)
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(MG_ACT_MAX_THREADS) void mg_act_kernel(KArgs a) {
   ActLds x;
   mg_carve_act<true>(smem, &l, &x, BIG ? 0 : a.HW, BIG ? 0 : a.A, a.A, a.NAmax, a.NCmax, a.SG, a.NWIN, DCL ? a.dc_words : 0);
   if (BIG) {
-    l.grid = a.big_grid + (size_t)e * a.HW;
+    l.grid = a.big_grid + (size_t)e * a.BHW;
     l.ag = a.agents + (size_t)e * a.A;
     l.ch = a.chests + (size_t)e * a.NCmax;
   }

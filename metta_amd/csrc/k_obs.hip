@@ -15,7 +15,7 @@ __global__ __launch_bounds__(BIG ? MG_OBS_BIG_THREADS : MG_THREADS, BIG ? 1 : MG
   mg_carve_obs<true>(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.ROWB, nt >> 6, DCL ? a.dc_obs_words : 0, a.NOBJ, a.HEAP,
                a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
-    l.grid = a.big_grid + (size_t)e * a.HW;
+    l.grid = a.big_grid + (size_t)e * a.BHW;
     l.ag = a.agents + (size_t)e * a.A;
     l.ch = a.chests + (size_t)e * a.NCmax;
   }

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(MG_THREADS) void mg_reset_kernel(KArgs a) {
   mg_carve<true>(smem, &l, BIG ? 0 : a.HW, a.A, a.NAmax, a.SA, a.SG, a.NWIN, a.ROWB, nt >> 6, 0, a.NOBJ, a.HEAP,
            a.dc[DC_PATTERN_N], BIG ? 0 : a.A, a.NCmax);
   if (BIG) {
-    l.grid = a.big_grid + (size_t)e * a.HW;
+    l.grid = a.big_grid + (size_t)e * a.BHW;
     l.ag = a.agents + (size_t)e * a.A;
     l.ch = a.chests + (size_t)e * a.NCmax;
   }

@@ -619,9 +619,17 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
   h->big = big;
   k.big_grid = nullptr;
   k.grid_valid = nullptr;
+  k.GPAD = 0;
+  k.BHW = HWp;
   if (big) {
     uint16_t* bg = nullptr;
-    if (dalloc(h, &bg, (size_t)std::max(h->E, num_maps) * HWp, true)) return 1;
+    k.GPAD = c.obs_w >> 1;
+    {
+      size_t m = 0;
+      for (int i = 0; i < num_maps; i++) m = std::max(m, (size_t)heights[i] * (size_t)(widths[i] + k.GPAD));
+      k.BHW = (int)((m + 7) & ~(size_t)7);
+    }
+    if (dalloc(h, &bg, (size_t)std::max(h->E, num_maps) * (size_t)k.BHW, true)) return 1;
     k.big_grid = bg;
     if (dalloc(h, &k.grid_valid, (size_t)h->E, true)) return 1;  // (zeroed: no grid holds an episode yet)
     HIPCHK(hipMemset(k.grid_valid, 0, (size_t)h->E));
@@ -802,7 +810,7 @@ static int mg_set_maps_impl(mg_handle* h, const uint8_t* maps, int num_maps, con
     if (dalloc(h, &d_maps, P, true)) return 1;
     if (big) {  // template builds must not touch the live grids of the environments
       uint16_t* tg = nullptr;
-      if (dalloc(h, &tg, P * (size_t)HWp, true)) return 1;
+      if (dalloc(h, &tg, P * (size_t)k.BHW, true)) return 1;
       kt.big_grid = tg;
       kt.grid_valid = nullptr;
     }

@@ -49,6 +49,8 @@ struct KArgs {
   int NCmax, TSC;             // chest slots per map; token-list stride of a chest
   const float* map_objcount;  // [P][n_cells]
   uint16_t* big_grid;         // [max(E, P)][HW] per-env grid in HBM for maps that do not fit LDS (BIG kernels), else null
+  int GPAD, BHW;              // BIG: rows of big_grid are W + GPAD cells long, the GPAD cells after each row zero (= obs_w / 2,
+                              // as PADC for the byte maps); BHW = cell stride of one environment's grid.  0 / HW otherwise
   uint8_t* grid_valid;        // [E] BIG: big_grid[e] holds the running episode's map with the agents where they stand now
                               // (the action kernel moves them in place), so a step neither copies the map nor overlays
                               // the agents again; cleared by whatever replaces the pool, null for template builds
@@ -324,6 +326,14 @@ __host__ __device__ inline size_t mg_carve_uses(unsigned char* base, Lds* l, int
 // ------------------------------------------------------------------------------------------------------------
 __device__ inline void mg_load_grid(const KArgs& a, const Lds& l, int map_id, int tid, int nt) {
   const uint16_t* src = a.map_cells + (size_t)map_id * a.HW;
+  if (a.GPAD) {  // a grid kept in HBM: rows padded with GPAD empty cells (window lookups need no column test)
+    const int Wp = a.W + a.GPAD, n = a.H * Wp;
+    for (int i = tid; i < n; i += nt) {
+      const int r = i / Wp, c = i - r * Wp;
+      l.grid[i] = c < a.W ? src[r * a.W + c] : (uint16_t)0;
+    }
+    return;
+  }
   int n2 = a.HW >> 1;
   const uint32_t* s32 = (const uint32_t*)src;  // HW*2 bytes per map; maps start 4-byte aligned (HW even or padded)
   uint32_t* d32 = (uint32_t*)l.grid;
@@ -339,7 +349,7 @@ template <class CT = uint16_t>
 __device__ inline void mg_overlay_agents(const KArgs& a, const Lds& l, int tid, int nt) {
   const CellCodec cc{a.NW, a.A, a.NAmax};
   CT* grid = (CT*)l.grid;
-  for (int i = tid; i < a.A; i += nt) grid[(int)l.ag[i].r * a.W + l.ag[i].c] = (CT)cc.agent(i);
+  for (int i = tid; i < a.A; i += nt) grid[(int)l.ag[i].r * (a.W + a.GPAD) + l.ag[i].c] = (CT)cc.agent(i);
 }
 
 __device__ __forceinline__ int mg_heap_off(const KArgs& a, int obj) {
@@ -376,7 +386,7 @@ __device__ inline void mg_build_tokens(const KArgs& a, const Lds& l, int map_id,
     const int ho = mg_heap_off(a, obj);
     PairOut out{l.heap + ho, 0};
     if (obj < a.NW + a.A + nasm || (obj >= first_chest && obj < first_chest + nchest))
-      mg_object_tokens(dc, (const CT*)l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
+      mg_object_tokens(dc, (const CT*)l.grid, l.ag, l.as, asm_info, cc, a.H, a.W, a.W + a.GPAD, step, (uint16_t)(obj + 1), out, l.ch, chest_info);
     l.ocnt[obj] = (uint32_t)ho | ((uint32_t)out.n << 16);
   }
   if (tid == 0) l.ocnt[-1] = 0;  // cell code 0 (empty) looks up "no tokens" without a branch
@@ -419,7 +429,7 @@ __device__ inline void mg_build_tokens_fused(const KArgs& a, const Lds& l, int m
     }
     if (!done) {
       PairOut out{l.heap + ho, 0};
-      mg_object_tokens(dc, (const uint8_t*)nullptr, l.ag, l.as, l.ainfo, cc, a.H, a.W, step, (uint16_t)(obj + 1), out, l.ch, a.map_chest);
+      mg_object_tokens(dc, (const uint8_t*)nullptr, l.ag, l.as, l.ainfo, cc, a.H, a.W, a.W + a.GPAD, step, (uint16_t)(obj + 1), out, l.ch, a.map_chest);
       n = out.n;
     }
     l.ocnt[obj] = (uint32_t)ho | ((uint32_t)n << 16);
@@ -444,10 +454,10 @@ __device__ inline void mg_build_asm_templates(const KArgs& a, const Lds& l, int 
         DAsm tmp = {0u, 0u, 0u, 0u};
         const DAsm* fake = &tmp - i;  // (mg_object_tokens indexes the record array by the station's index)
         PairOut idle{dst, 0};
-        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, 0u, cc.assembler(i), idle);
+        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, a.W + a.GPAD, 0u, cc.assembler(i), idle);
         tmp.cooldown_end = 1u;  // step 0: one tick left -- the value is patched in every step
         PairOut cooling{dst + a.TSS, 0};
-        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, 0u, cc.assembler(i), cooling);
+        mg_object_tokens(dc, (const CT*)l.grid, l.ag, fake, l.ainfo, cc, a.H, a.W, a.W + a.GPAD, 0u, cc.assembler(i), cooling);
         n = (cooling.n == idle.n + 1 && idle.n < 255) ? idle.n : 255;
       }
     }
@@ -524,7 +534,7 @@ __device__ __forceinline__ void mg_window_lookup(const KArgs& a, const Lds& l, c
     int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
     const bool ok = p < P && (unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && (HOT || !(a.diag & 512));
     // no branches: cells outside the map read cell 0 and are masked; empty cells read the zero entry ocnt[-1]
-    const uint32_t cv = ((const CT*)l.grid)[ok ? __mul24(r, W) + c : 0];
+    const uint32_t cv = ((const CT*)l.grid)[ok ? __mul24(r, W + a.GPAD) + c : 0];
     meta[q] = l.ocnt[(int)(ok ? cv : 0u) - 1];
   }
 }
@@ -790,19 +800,30 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
   const DAgent* me0 = l.ag + wave * group;
   const uint32_t roff_step = (uint32_t)(nwaves * group) * (uint32_t)row_bytes;
   uint32_t cvn[group][NR], rcn[group];  // PF: the next group's positions and raw grid cells, in flight
+  // PF: the environment's grid in HBM behind a buffer descriptor, rows padded by GPAD empty cells: a window cell is
+  // position + offset (dlt, in cells of the padded grid), cells above / below the map fall outside the descriptor and
+  // read 0, cells left / right of it land on padding -- no row or column test on the vector unit.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int Wg = ec.W + a.GPAD;
+  __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)l.grid, 0, PF ? __mul24(ec.H, Wg) * 2 : 0, 0x00020000);
+  int dlg[MG_MAX_ROUNDS];
+#pragma unroll
+  for (int q = 0; q < MG_MAX_ROUNDS; q++) {
+    const bool in_pat = q < NR && (q * 64 + lane) < ec.P;
+    dlg[q] = in_pat ? (__mul24((int)(pk[q] & 0xFF) - 8, Wg) + (int)((pk[q] >> 8) & 0xFF) - 8) * 2 : 0x40000000;
+  }
+#endif
   auto request = [&](int first) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int h = 0; h < group; h++) {
       const uint32_t p = first + h < a.A ? l.pos[first + h] : 0u;
       rcn[h] = p;
-      const int ar = (int)(p & 0xFFFF), ac = (int)(p >> 16);
+      const int base = (__mul24((int)(p & 0xFFFF), Wg) + (int)(p >> 16)) * 2;
 #pragma unroll
-      for (int q = 0; q < NR; q++) {
-        const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
-        const bool ok = (q * 64 + lane) < ec.P && (unsigned)r < (unsigned)ec.H && (unsigned)c < (unsigned)ec.W;
-        cvn[h][q] = ((const CT*)l.grid)[ok ? __mul24(r, ec.W) + c : 0];
-      }
+      for (int q = 0; q < NR; q++) cvn[h][q] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(grsrc, base + dlg[q], 0, 0);
     }
+#endif
   };
   if (PF) request(wave * group);
   for (int a0 = wave * group; a0 < a.A; a0 += nwaves * group, roff0 += roff_step, me0 += nwaves * group)
@@ -812,13 +833,8 @@ __device__ __forceinline__ void mg_encode_all_t(const KArgs& a, const Lds& l, in
 #pragma unroll
       for (int h = 0; h < group; h++) {
         rc[h] = rcn[h];
-        const int ar = (int)(rc[h] & 0xFFFF), ac = (int)(rc[h] >> 16);
 #pragma unroll
-        for (int q = 0; q < NR; q++) {
-          const int r = ar + (int)(pk[q] & 0xFF) - 8, c = ac + (int)((pk[q] >> 8) & 0xFF) - 8;
-          const bool ok = (q * 64 + lane) < ec.P && (unsigned)r < (unsigned)ec.H && (unsigned)c < (unsigned)ec.W;
-          meta[h][q] = l.ocnt[(int)(ok ? cvn[h][q] : 0u) - 1];
-        }
+        for (int q = 0; q < NR; q++) meta[h][q] = l.ocnt[(int)cvn[h][q] - 1];
       }
       if (a0 + nwaves * group < a.A) request(a0 + nwaves * group);
     }
@@ -941,10 +957,10 @@ __device__ inline void mg_recount_initial_tokens(const KArgs& a, const Lds& l, i
     const uint32_t pk = mg_pattern_entry(a.gdc, p);
     const int r = (int)l.ag[ai].r + (int)(pk & 0xFF) - 8, c = (int)l.ag[ai].c + (int)((pk >> 8) & 0xFF) - 8;
     if ((unsigned)r >= (unsigned)ec.H || (unsigned)c >= (unsigned)ec.W) continue;
-    const uint16_t cv = (uint16_t)grid[r * ec.W + c];
+    const uint16_t cv = (uint16_t)grid[r * (ec.W + a.GPAD) + c];
     if (cv == 0) continue;
     CountOut n2{0};
-    mg_object_tokens(dc, grid, l.ag, l.as, asm_info, cc, ec.H, ec.W, 0u, cv, n2, l.ch, chest_info);
+    mg_object_tokens(dc, grid, l.ag, l.as, asm_info, cc, ec.H, ec.W, ec.W + a.GPAD, 0u, cv, n2, l.ch, chest_info);
     int n1 = n2.n;
     if (cc.kind(cv) == MG_CELL_ASSEMBLER && l.as[cc.asm_idx(cv)].clipped >= 2u) {
       // before the Clipper was built the station was plainly clipped: the flag, no protocol tokens
@@ -952,7 +968,7 @@ __device__ inline void mg_recount_initial_tokens(const KArgs& a, const Lds& l, i
       before.clipped = 1u;
       CountOut c1{0};
       // (the station list is indexed by the cell's station index: hand over a pointer that puts `before` there)
-      mg_object_tokens(dc, grid, l.ag, &before - cc.asm_idx(cv), asm_info, cc, ec.H, ec.W, 0u, cv, c1, l.ch, chest_info);
+      mg_object_tokens(dc, grid, l.ag, &before - cc.asm_idx(cv), asm_info, cc, ec.H, ec.W, ec.W + a.GPAD, 0u, cv, c1, l.ch, chest_info);
       n1 = c1.n;
     }
     atomicAdd(&att1[ai], n1);
@@ -1234,7 +1250,7 @@ __device__ inline void mg_make_ctx(const KArgs& a, const Lds& l, Ctx& cx, int e,
   cx.dirty_amt = l.dirty_amt;
   cx.tmp = l.tmp;
   cx.dirty_misc = l.dirty_misc;
-  cx.H = a.H; cx.W = a.W; cx.A = a.A; cx.NA = a.NAmax; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG;
+  cx.H = a.H; cx.W = a.W; cx.GW = a.W + a.GPAD; cx.A = a.A; cx.NA = a.NAmax; cx.R = a.R; cx.SA = a.SA; cx.SG = a.SG; cx.NG = a.NG;
   cx.step = step;
   cx.asm_dirty = 0;
   cx.AS = MgAgentSlots{a.R, a.NG};

@@ -93,6 +93,7 @@ struct Ctx {
   unsigned long long* gset64;
   uint32_t seq;
   int H, W, A, NA, R, SA, SG, NG;
+  int GW;                             // row stride of `grid` (W, or W + padding for the grids kept in HBM)
   uint32_t step;
   int asm_dirty;
   int overflow;                       // a fixed-size work list was too small (more than 24 chests around an assembler)
@@ -491,7 +492,7 @@ __device__ inline int mg_select_protocol(const int* dc, int cfg, unsigned long l
 // Assembler::get_current_protocol on the grid as it stands (assembler.hpp:353-408).
 template <class CT>
 __device__ inline int mg_current_protocol(const int* dc, const CT* grid, const DAgent* ag, CellCodec codec, int H,
-                                          int W, int ar, int ac, int cfg, uint32_t clipped) {
+                                          int W, int GW, int ar, int ac, int cfg, uint32_t clipped) {
   unsigned long long vibes = 0;
   int n_agents = 0;
   if (!grid) {  // no occupancy tile (fused kernel): the surrounding agents by position (any order: the key is sorted)
@@ -509,7 +510,7 @@ __device__ inline int mg_current_protocol(const int* dc, const CT* grid, const D
       if (i == 0 && j == 0) continue;
       int rr = ar + i, cc = ac + j;
       if (rr < 0 || cc < 0 || rr >= H || cc >= W) continue;
-      uint16_t cv = grid[rr * W + cc];
+      uint16_t cv = grid[rr * GW + cc];
       if (codec.is_agent(cv)) {
         vibes |= (unsigned long long)ag[codec.agent_idx(cv)].vibe << (8 * n_agents);
         n_agents++;
@@ -686,7 +687,7 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
         seen++;
       }
     int o9 = q < 4 ? q : q + 1;
-    uint16_t cv = cx.grid[(ar + o9 / 3 - 1) * cx.W + (ac + o9 % 3 - 1)];
+    uint16_t cv = cx.grid[(ar + o9 / 3 - 1) * cx.GW + (ac + o9 % 3 - 1)];
     if (cx.cc.is_agent(cv)) {
       near[nn] = cx.cc.agent_idx(cv);
       vibes[nn] = cx.ag[near[nn]].vibe;
@@ -704,7 +705,7 @@ __device__ inline bool mg_assembler_use(Ctx& cx, int ai_actor, int asm_idx) {
       if (dr == 0 && dcl == 0) continue;
       int rr = ar + dr, c2 = ac + dcl;
       if (rr < 0 || c2 < 0 || rr >= cx.H || c2 >= cx.W) continue;
-      uint16_t cv = cx.grid[rr * cx.W + c2];
+      uint16_t cv = cx.grid[rr * cx.GW + c2];
       if (cx.cc.is_chest(cv) && n_inputs < 32) inputs[n_inputs++] = cx.A + cx.cc.chest_idx(cv);
       else if (cx.cc.is_chest(cv)) cx.overflow = 1;
     }
@@ -842,7 +843,7 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
   DAgent* actor = &cx.ag[ai];
   int tr = (int)actor->r + DY[orientation], tc = (int)actor->c + DX[orientation];
   if (tr < 0 || tc < 0 || tr >= cx.H || tc >= cx.W) return false;
-  uint16_t target = cx.grid[tr * cx.W + tc];
+  uint16_t target = cx.grid[tr * cx.GW + tc];
   int vh = cx.dc[cx.dc[DC_OFF_VIBE_HANDLER] + actor->vibe];
   if (vh == MG_VH_ATTACK) {
     if (mg_try_attack(cx, ai, target)) return true;
@@ -851,8 +852,8 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
   }
   int kind = cx.cc.kind(target);
   if (kind == MG_CELL_EMPTY) {
-    cx.grid[tr * cx.W + tc] = cx.cc.agent(ai);
-    cx.grid[(int)actor->r * cx.W + actor->c] = 0;
+    cx.grid[tr * cx.GW + tc] = cx.cc.agent(ai);
+    cx.grid[(int)actor->r * cx.GW + actor->c] = 0;
     actor->r = (uint16_t)tr;
     actor->c = (uint16_t)tc;
     return true;
@@ -861,8 +862,8 @@ __device__ inline bool mg_do_move(Ctx& cx, int ai, int orientation) {
     int ti = cx.cc.agent_idx(target);
     DAgent* ta = &cx.ag[ti];
     if (ta->frozen > 0) {
-      cx.grid[(int)actor->r * cx.W + actor->c] = cx.cc.agent(ti);
-      cx.grid[tr * cx.W + tc] = cx.cc.agent(ai);
+      cx.grid[(int)actor->r * cx.GW + actor->c] = cx.cc.agent(ti);
+      cx.grid[tr * cx.GW + tc] = cx.cc.agent(ai);
       ta->r = actor->r;
       ta->c = actor->c;
       actor->r = (uint16_t)tr;
@@ -1116,7 +1117,7 @@ __device__ inline void mg_inventory_tokens(const int* dc, const DAgent* a, OUT& 
 
 template <class OUT, class CT>
 __device__ inline void mg_object_tokens(const int* dc, const CT* grid, const DAgent* ag, const DAsm* as,
-                                        const int4* asm_info, CellCodec cc, int H, int W, uint32_t step, uint16_t cv,
+                                        const int4* asm_info, CellCodec cc, int H, int W, int GW, uint32_t step, uint16_t cv,
                                         OUT& out, const DAgent* chests = nullptr, const int4* chest_info = nullptr) {
   int kind = cc.kind(cv);
   const int f_tag = dc[DC_FID0 + MG_F_TAG], f_vibe = dc[DC_FID0 + MG_F_VIBE];
@@ -1153,10 +1154,10 @@ __device__ inline void mg_object_tokens(const int* dc, const CT* grid, const DAg
       int po = rec[AR_SIMPLE_PO];
 #ifdef MG_NO_CLIPPER
       if (s->clipped) po = -1;
-      else if (po < 0) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, 0u);
+      else if (po < 0) po = mg_current_protocol(dc, grid, ag, cc, H, W, GW, info.x, info.y, info.z, 0u);
 #else
       if (s->clipped == 1u) po = -1;
-      else if (po < 0 || s->clipped) po = mg_current_protocol(dc, grid, ag, cc, H, W, info.x, info.y, info.z, s->clipped);
+      else if (po < 0 || s->clipped) po = mg_current_protocol(dc, grid, ag, cc, H, W, GW, info.x, info.y, info.z, s->clipped);
 #endif
       if (po >= 0) {
         int oi = dc[po + PR_OFF_IN], ni = L_n(dc, oi);
