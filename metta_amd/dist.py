@@ -51,7 +51,7 @@ def bench_workload(name: str, small: bool = False) -> dict:
         cfg = make_combat_stress(agents, side)
         return {
             "name": name, "cfg": cfg, "maps": [cfg.game.map_builder.build(np.random.default_rng(i)) for i in range(4)],
-            "agents": agents, "envs": 64, "num_actions": 8, "groups": 1,
+            "agents": agents, "envs": 256, "num_actions": 8, "groups": 1,  # (one environment per CU: 64 leave 3/4 of the GPU idle)
             "describe": f"combat-stress envs x {agents} agents on {side}x{side} maps per GPU (BASELINE configs[3])",
         }  # fmt: skip
     raise ValueError(f"unknown workload {name!r}: arena, combat or rollout")
